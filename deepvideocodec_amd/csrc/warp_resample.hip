@@ -1,0 +1,364 @@
+// HBM-bound geometry / resampling kernels of the DMC path: backward flow warp
+// (bilinear gather), 2x2 mean / max pooling, bilinear x2 upsampling, the fused
+// SpyNet level input, the squeeze-excite gate and strided copy / clamp.
+// One lane per output pixel (consecutive lanes = consecutive x, so loads and
+// stores of a wave are contiguous 256-byte rows); channels are looped inside the
+// lane so the per-pixel coordinate math is done once for all channels.
+#include "dvc_common.h"
+
+namespace {
+
+using dvc::stream_grid;
+
+struct Src { const float* p; long long bs, cs; int c; };
+struct Dst { float* p; long long bs, cs; };
+
+inline Src mk(const DvcSrc* s) { return Src{s->ptr, s->batch_stride, s->chan_stride, s->channels}; }
+inline Dst mk(const DvcDst* d) { return Dst{d->ptr, d->batch_stride, d->chan_stride}; }
+
+// torch.linspace(-1, 1, steps)[idx] in fp32 (symmetric two-sided formula).
+__device__ __forceinline__ float linspace_pm1(int idx, int steps) {
+  const float step = 2.0f / (float)(steps - 1);
+  const int halfway = steps / 2;
+  return idx < halfway ? -1.0f + step * (float)idx : 1.0f - step * (float)(steps - idx - 1);
+}
+
+struct Bilin {
+  int o_nw, o_ne, o_sw, o_se;  // plane offsets (clamped in-bounds)
+  float nw, ne, sw, se;
+};
+
+// Sampling position for output pixel (y,x) displaced by (u,v) pixels, following the
+// reference's arithmetic: normalised base grid + flow / ((size-1)/2), then
+// grid_sample's un-normalise ((g+1) * (size-1)/2), border clip, floor, weights.
+__device__ __forceinline__ Bilin bilin_setup(int y, int x, float u, float v, int h, int w) {
+  const float sx = (float)((w - 1.0) / 2.0), sy = (float)((h - 1.0) / 2.0);
+  float gx = linspace_pm1(x, w) + u / sx;
+  float gy = linspace_pm1(y, h) + v / sy;
+  if (w == 1) gx = -1.0f + u / sx;  // linspace with one step is `start`
+  if (h == 1) gy = -1.0f + v / sy;
+  float fx = (gx + 1.0f) * sx, fy = (gy + 1.0f) * sy;
+  fx = fminf((float)(w - 1), fmaxf(fx, 0.0f));
+  fy = fminf((float)(h - 1), fmaxf(fy, 0.0f));
+  const float xw = floorf(fx), yn = floorf(fy);
+  const float we = fx - xw, ee = 1.0f - we, ns = fy - yn, ss = 1.0f - ns;
+  Bilin b;
+  b.nw = ss * ee; b.ne = ss * we; b.sw = ns * ee; b.se = ns * we;
+  const int ix = (int)xw, iy = (int)yn;
+  const int ix1 = ix + 1 < w ? ix + 1 : ix;   // out-of-range neighbour has weight 0
+  const int iy1 = iy + 1 < h ? iy + 1 : iy;
+  if (ix + 1 >= w) { b.ne = 0.f; b.se = 0.f; }
+  if (iy + 1 >= h) { b.sw = 0.f; b.se = 0.f; }
+  b.o_nw = iy * w + ix; b.o_ne = iy * w + ix1; b.o_sw = iy1 * w + ix; b.o_se = iy1 * w + ix1;
+  return b;
+}
+
+__device__ __forceinline__ float bilin_fetch(const float* plane, const Bilin& b) {
+  return plane[b.o_nw] * b.nw + plane[b.o_ne] * b.ne + plane[b.o_sw] * b.sw + plane[b.o_se] * b.se;
+}
+
+__global__ __launch_bounds__(256) void flow_warp_kernel(Src src, Src flow, Dst out, int batch, int h, int w) {
+  const long long hw = (long long)h * w, total = hw * batch;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / hw);
+    const int pix = (int)(i - n * hw);
+    const int y = pix / w, x = pix - y * w;
+    const float* fp = flow.p + n * flow.bs + pix;
+    const Bilin b = bilin_setup(y, x, fp[0], fp[flow.cs], h, w);
+    const float* sp = src.p + n * src.bs;
+    float* op = out.p + n * out.bs + pix;
+    for (int c = 0; c < src.c; ++c) op[c * out.cs] = bilin_fetch(sp + c * src.cs, b);
+  }
+}
+
+// Flat index over (n, c, oy, ox) of the output.
+#define DVC_FOREACH_OUT(total_expr)                                                     \
+  const long long total_ = (total_expr);                                                \
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_; i += (long long)gridDim.x * 256)
+
+__global__ __launch_bounds__(256) void avg_pool2_kernel(Src src, Dst out, int batch, int h, int w, float scale) {
+  const int ho = h / 2, wo = w / 2;
+  DVC_FOREACH_OUT((long long)batch * src.c * ho * wo) {
+    const int ox = (int)(i % wo);
+    long long t = i / wo;
+    const int oy = (int)(t % ho); t /= ho;
+    const int c = (int)(t % src.c), n = (int)(t / src.c);
+    const float* p = src.p + n * src.bs + c * src.cs + (long long)(2 * oy) * w + 2 * ox;
+    // bilinear half-pixel weights are all .5: .5*(.5a+.5b) + .5*(.5c+.5d)
+    const float v = 0.5f * (0.5f * p[0] + 0.5f * p[1]) + 0.5f * (0.5f * p[w] + 0.5f * p[w + 1]);
+    out.p[n * out.bs + c * out.cs + (long long)oy * wo + ox] = v * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void max_pool2_kernel(Src src, Dst out, int batch, int h, int w) {
+  const int ho = h / 2, wo = w / 2;
+  DVC_FOREACH_OUT((long long)batch * src.c * ho * wo) {
+    const int ox = (int)(i % wo);
+    long long t = i / wo;
+    const int oy = (int)(t % ho); t /= ho;
+    const int c = (int)(t % src.c), n = (int)(t / src.c);
+    const float* p = src.p + n * src.bs + c * src.cs + (long long)(2 * oy) * w + 2 * ox;
+    out.p[n * out.bs + c * out.cs + (long long)oy * wo + ox] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[w], p[w + 1]));
+  }
+}
+
+// align_corners=False x2: src = .5*(dst+.5)-.5 clamped at 0; i1 = min(i0+1, in-1).
+__device__ __forceinline__ void up2_coord(int o, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__device__ __forceinline__ float up2_sample(const float* plane, int w_in, int y0, int y1, float ly0, float ly1,
+                                            int x0, int x1, float lx0, float lx1) {
+  return ly0 * (lx0 * plane[y0 * w_in + x0] + lx1 * plane[y0 * w_in + x1]) +
+         ly1 * (lx0 * plane[y1 * w_in + x0] + lx1 * plane[y1 * w_in + x1]);
+}
+
+__global__ __launch_bounds__(256) void bilinear_up2_kernel(Src src, Dst out, int batch, int h, int w, float scale) {
+  const int ho = 2 * h, wo = 2 * w;
+  DVC_FOREACH_OUT((long long)batch * src.c * ho * wo) {
+    const int ox = (int)(i % wo);
+    long long t = i / wo;
+    const int oy = (int)(t % ho); t /= ho;
+    const int c = (int)(t % src.c), n = (int)(t / src.c);
+    int x0, x1, y0, y1; float lx0, lx1, ly0, ly1;
+    up2_coord(ox, w, x0, x1, lx0, lx1);
+    up2_coord(oy, h, y0, y1, ly0, ly1);
+    const float* p = src.p + n * src.bs + c * src.cs;
+    out.p[n * out.bs + c * out.cs + (long long)oy * wo + ox] =
+        up2_sample(p, w, y0, y1, ly0, ly1, x0, x1, lx0, lx1) * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void spynet_level_input_kernel(Src im1, Src im2, Src flow_prev, Dst out,
+                                                                int batch, int h, int w) {
+  const long long hw = (long long)h * w, total = hw * batch;
+  const int hp = h / 2, wp = w / 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / hw);
+    const int pix = (int)(i - n * hw);
+    const int y = pix / w, x = pix - y * w;
+    float u = 0.f, v = 0.f;
+    if (flow_prev.p != nullptr) {
+      int x0, x1, y0, y1; float lx0, lx1, ly0, ly1;
+      up2_coord(x, wp, x0, x1, lx0, lx1);
+      up2_coord(y, hp, y0, y1, ly0, ly1);
+      const float* fp = flow_prev.p + n * flow_prev.bs;
+      u = up2_sample(fp, wp, y0, y1, ly0, ly1, x0, x1, lx0, lx1) * 2.0f;
+      v = up2_sample(fp + flow_prev.cs, wp, y0, y1, ly0, ly1, x0, x1, lx0, lx1) * 2.0f;
+    }
+    const Bilin b = bilin_setup(y, x, u, v, h, w);
+    float* op = out.p + n * out.bs + pix;
+    const float* p1 = im1.p + n * im1.bs + pix;
+    const float* p2 = im2.p + n * im2.bs;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      op[c * out.cs] = p1[c * im1.cs];
+      op[(3 + c) * out.cs] = bilin_fetch(p2 + c * im2.cs, b);
+    }
+    op[6 * out.cs] = u;
+    op[7 * out.cs] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(Src src, Dst out, int batch, int h, int w) {
+  const long long hw = (long long)h * w;
+  DVC_FOREACH_OUT((long long)batch * src.c * hw) {
+    const long long pix = i % hw;
+    long long t = i / hw;
+    const int c = (int)(t % src.c), n = (int)(t / src.c);
+    out.p[n * out.bs + c * out.cs + pix] = src.p[n * src.bs + c * src.cs + pix];
+  }
+}
+
+__global__ __launch_bounds__(256) void clamp_kernel(Src src, Dst out, int batch, int h, int w, float lo, float hi) {
+  const long long hw = (long long)h * w;
+  DVC_FOREACH_OUT((long long)batch * src.c * hw) {
+    const long long pix = i % hw;
+    long long t = i / hw;
+    const int c = (int)(t % src.c), n = (int)(t / src.c);
+    const float v = src.p[n * src.bs + c * src.cs + pix];
+    out.p[n * out.bs + c * out.cs + pix] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
+// ---------------------------------------------------------------- squeeze-excite
+constexpr int SE_SLICES = 64;  // partial sums per (n, c) plane
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum of 256 per-thread values, result valid in thread 0.  Fixed order.
+__device__ __forceinline__ float block_sum_256(float v, float* lds4) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void plane_partial_sum_kernel(Src x, int h, int w, float* partial) {
+  __shared__ float red[4];
+  const int slice = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const long long hw = (long long)h * w;
+  const long long per = (hw + SE_SLICES - 1) / SE_SLICES;
+  const long long b = slice * per, e = b + per < hw ? b + per : hw;
+  const float* p = x.p + n * x.bs + c * x.cs;
+  float s = 0.f;
+  for (long long i = b + threadIdx.x; i < e; i += 256) s += p[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[((long long)n * x.c + c) * SE_SLICES + slice] = s;
+}
+
+// one block per n: mean -> fc1 -> relu -> fc2 -> sigmoid
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* partial, int channels, int hidden, float inv_hw,
+                                                    const float* fc1, const float* fc2, float* gate) {
+  __shared__ float mean_s[256];
+  __shared__ float hid_s[64];
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t < channels) {
+    const float* pp = partial + ((long long)n * channels + t) * SE_SLICES;
+    float s = 0.f;
+    for (int k = 0; k < SE_SLICES; ++k) s += pp[k];
+    mean_s[t] = s * inv_hw;
+  }
+  __syncthreads();
+  if (t < hidden) {
+    float s = 0.f;
+    for (int c = 0; c < channels; ++c) s += fc1[t * channels + c] * mean_s[c];
+    hid_s[t] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  if (t < channels) {
+    float s = 0.f;
+    for (int j = 0; j < hidden; ++j) s += fc2[t * hidden + j] * hid_s[j];
+    gate[(long long)n * channels + t] = 1.0f / (1.0f + expf(-s));
+  }
+}
+
+int check_plane(const DvcSrc* s, int h, int w, const char* who) {
+  DVC_REQUIRE(s != nullptr && s->ptr != nullptr && s->channels >= 1, "%s: null/empty source", who);
+  DVC_REQUIRE(s->chan_stride >= (int64_t)h * w, "%s: channel stride < H*W", who);
+  return DVC_OK;
+}
+
+}  // namespace
+
+#define DVC_CHECK_SRC(s, h, w, who) do { int rc_ = check_plane((s), (h), (w), (who)); if (rc_) return rc_; } while (0)
+#define DVC_CHECK_DST(d, plane, who)                                                   \
+  DVC_REQUIRE((d) != nullptr && (d)->ptr != nullptr && (d)->chan_stride >= (int64_t)(plane), "%s: bad destination", who)
+
+extern "C" int dvc_flow_warp(const DvcSrc* src, const DvcSrc* flow, const DvcDst* out, int32_t batch, int32_t h,
+                             int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_flow_warp: bad dims");
+  DVC_CHECK_SRC(src, h, w, "dvc_flow_warp(src)");
+  DVC_CHECK_SRC(flow, h, w, "dvc_flow_warp(flow)");
+  DVC_REQUIRE(flow->channels == 2, "dvc_flow_warp: flow must have 2 channels");
+  DVC_CHECK_DST(out, (int64_t)h * w, "dvc_flow_warp");
+  DVC_REQUIRE((int64_t)h * w < (1LL << 30), "dvc_flow_warp: plane too large");
+  const long long total = (long long)batch * h * w;
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src),
+                     mk(flow), mk(out), batch, h, w);
+  return dvc::check_launch("flow_warp_kernel");
+}
+
+extern "C" int dvc_avg_pool2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w, float scale,
+                             void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "dvc_avg_pool2: H, W must be even");
+  DVC_CHECK_SRC(src, h, w, "dvc_avg_pool2");
+  DVC_CHECK_DST(out, (int64_t)(h / 2) * (w / 2), "dvc_avg_pool2");
+  const long long total = (long long)batch * src->channels * (h / 2) * (w / 2);
+  hipLaunchKernelGGL(avg_pool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src),
+                     mk(out), batch, h, w, scale);
+  return dvc::check_launch("avg_pool2_kernel");
+}
+
+extern "C" int dvc_max_pool2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                             void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "dvc_max_pool2: H, W must be even");
+  DVC_CHECK_SRC(src, h, w, "dvc_max_pool2");
+  DVC_CHECK_DST(out, (int64_t)(h / 2) * (w / 2), "dvc_max_pool2");
+  const long long total = (long long)batch * src->channels * (h / 2) * (w / 2);
+  hipLaunchKernelGGL(max_pool2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src),
+                     mk(out), batch, h, w);
+  return dvc::check_launch("max_pool2_kernel");
+}
+
+extern "C" int dvc_bilinear_up2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                                float scale, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_bilinear_up2: bad dims");
+  DVC_CHECK_SRC(src, h, w, "dvc_bilinear_up2");
+  DVC_CHECK_DST(out, (int64_t)4 * h * w, "dvc_bilinear_up2");
+  const long long total = (long long)batch * src->channels * 4 * h * w;
+  hipLaunchKernelGGL(bilinear_up2_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src),
+                     mk(out), batch, h, w, scale);
+  return dvc::check_launch("bilinear_up2_kernel");
+}
+
+extern "C" int dvc_spynet_level_input(const DvcSrc* im1, const DvcSrc* im2, const DvcSrc* flow_prev,
+                                      const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "dvc_spynet_level_input: H, W must be even");
+  DVC_CHECK_SRC(im1, h, w, "dvc_spynet_level_input(im1)");
+  DVC_CHECK_SRC(im2, h, w, "dvc_spynet_level_input(im2)");
+  DVC_REQUIRE(im1->channels == 3 && im2->channels == 3, "dvc_spynet_level_input: images must have 3 channels");
+  Src fp{nullptr, 0, 0, 2};
+  if (flow_prev != nullptr && flow_prev->ptr != nullptr) {
+    DVC_CHECK_SRC(flow_prev, h / 2, w / 2, "dvc_spynet_level_input(flow_prev)");
+    DVC_REQUIRE(flow_prev->channels == 2, "dvc_spynet_level_input: flow must have 2 channels");
+    fp = mk(flow_prev);
+  }
+  DVC_CHECK_DST(out, (int64_t)h * w, "dvc_spynet_level_input");
+  const long long total = (long long)batch * h * w;
+  hipLaunchKernelGGL(spynet_level_input_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     mk(im1), mk(im2), fp, mk(out), batch, h, w);
+  return dvc::check_launch("spynet_level_input_kernel");
+}
+
+extern "C" int64_t dvc_se_scratch_floats(int32_t batch, int32_t channels) {
+  return (int64_t)batch * channels * SE_SLICES;
+}
+
+extern "C" int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1, const float* fc2,
+                           int32_t hidden, float* partial, float* gate, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_se_gate: bad dims");
+  DVC_CHECK_SRC(x, h, w, "dvc_se_gate");
+  DVC_REQUIRE(x->channels <= 256 && hidden >= 1 && hidden <= 64, "dvc_se_gate: channels<=256, hidden<=64 required");
+  DVC_REQUIRE(fc1 && fc2 && partial && gate, "dvc_se_gate: null pointer");
+  hipLaunchKernelGGL(plane_partial_sum_kernel, dim3(SE_SLICES, x->channels, batch), dim3(256), 0, (hipStream_t)stream,
+                     mk(x), h, w, partial);
+  int rc = dvc::check_launch("plane_partial_sum_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, x->channels,
+                     hidden, 1.0f / ((float)h * (float)w), fc1, fc2, gate);
+  return dvc::check_launch("se_fc_kernel");
+}
+
+extern "C" int dvc_copy(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_copy: bad dims");
+  DVC_CHECK_SRC(src, h, w, "dvc_copy");
+  DVC_CHECK_DST(out, (int64_t)h * w, "dvc_copy");
+  const long long total = (long long)batch * src->channels * h * w;
+  hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src), mk(out),
+                     batch, h, w);
+  return dvc::check_launch("copy_kernel");
+}
+
+extern "C" int dvc_clamp(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w, float lo,
+                         float hi, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_clamp: bad dims");
+  DVC_CHECK_SRC(src, h, w, "dvc_clamp");
+  DVC_CHECK_DST(out, (int64_t)h * w, "dvc_clamp");
+  const long long total = (long long)batch * src->channels * h * w;
+  hipLaunchKernelGGL(clamp_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src), mk(out),
+                     batch, h, w, lo, hi);
+  return dvc::check_launch("clamp_kernel");
+}

@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the libdvc_hip.so C ABI.
+
+torch is used for device memory and stream plumbing only: every arithmetic op
+here is a HIP kernel of this package launched on torch's current stream.
+All tensors must be fp32 (int32 for symbols / indexes) CUDA(HIP) tensors in
+NCHW with contiguous rows; batch / channel strides are free, so channel slices
+of a larger buffer are accepted as sources, residuals and destinations.
+"""
+import ctypes as C
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import DvcConv2d, DvcDst, DvcSrc, check
+
+Tensor = torch.Tensor
+Srcs = Union[Tensor, Sequence[Tensor]]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check4(t: Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.DvcError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() != 4:
+        raise ValueError(f"{name}: expected NCHW, got shape {tuple(t.shape)}")
+    if t.size(3) > 1 and t.stride(3) != 1 or (t.size(2) > 1 and t.stride(2) != t.size(3)):
+        raise ValueError(f"{name}: rows must be contiguous (strides {t.stride()})")
+
+
+def _bs(t: Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else t.size(1) * max(t.stride(1), t.size(2) * t.size(3))
+
+
+def _cs(t: Tensor) -> int:
+    return t.stride(1) if t.size(1) > 1 else t.size(2) * t.size(3)
+
+
+def _src(t: Tensor, name="src") -> DvcSrc:
+    _check4(t, name)
+    return DvcSrc(t.data_ptr(), _bs(t), _cs(t), t.size(1), 0)
+
+
+def _dst(t: Tensor, name="out") -> DvcDst:
+    _check4(t, name)
+    return DvcDst(t.data_ptr(), _bs(t), _cs(t))
+
+
+def _null_dst() -> DvcDst:
+    return DvcDst(None, 0, 0)
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
+           in_slope: Optional[float] = None, out_slope: Optional[float] = None,
+           residual: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
+           residual2: Optional[Tensor] = None, pixel_shuffle: bool = False,
+           out: Optional[Tensor] = None) -> Tensor:
+    """See DvcConv2d in include/dvc_hip.h. `srcs` are concatenated along C; slopes of
+    None mean "no activation", 0.0 means ReLU."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = (srcs,)
+    if not 1 <= len(srcs) <= _lib.DVC_MAX_SRC:
+        raise ValueError(f"conv2d: {len(srcs)} sources (1..{_lib.DVC_MAX_SRC} supported)")
+    p = DvcConv2d()
+    n, _, h, w = srcs[0].shape
+    cin = 0
+    for i, s in enumerate(srcs):
+        if s.shape[0] != n or s.shape[2] != h or s.shape[3] != w:
+            raise ValueError(f"conv2d: source {i} shape {tuple(s.shape)} does not match {(n, '*', h, w)}")
+        p.src[i] = _src(s, f"conv2d src[{i}]")
+        cin += s.size(1)
+    cout, wcin, k, k2 = weight.shape
+    if wcin != cin or k != k2:
+        raise ValueError(f"conv2d: weight {tuple(weight.shape)} does not match {cin} input channels")
+    if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32):
+        raise ValueError("conv2d: weight must be a contiguous fp32 GPU tensor")
+    pad = k // 2
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    oshape = (n, cout // 4, 2 * ho, 2 * wo) if pixel_shuffle else (n, cout, ho, wo)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=weight.device)
+    elif tuple(out.shape) != oshape:
+        raise ValueError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
+    p.n_src = len(srcs)
+    p.batch, p.in_h, p.in_w = n, h, w
+    p.weight = weight.data_ptr()
+    p.bias = _ptr(bias)
+    p.out_channels = cout
+    p.ksize = k
+    p.stride = stride
+    p.in_act = 0 if in_slope is None else 1
+    p.out_act = 0 if out_slope is None else 1
+    p.in_slope = 1.0 if in_slope is None else float(in_slope)
+    p.out_slope = 1.0 if out_slope is None else float(out_slope)
+    p.pixel_shuffle = 1 if pixel_shuffle else 0
+    p.out = _dst(out)
+    if residual is not None:
+        if tuple(residual.shape) != oshape:
+            raise ValueError(f"conv2d: residual shape {tuple(residual.shape)} != {oshape}")
+        _check4(residual, "conv2d residual")
+        p.residual = residual.data_ptr()
+        p.res_batch_stride = _bs(residual)
+        p.res_chan_stride = _cs(residual)
+    if res_scale is not None:
+        if residual is None or res_scale.numel() != n * oshape[1] or not res_scale.is_contiguous():
+            raise ValueError("conv2d: res_scale needs a residual and N*C contiguous entries")
+        p.res_scale = res_scale.data_ptr()
+    if residual2 is not None:
+        if residual is None or tuple(residual2.shape) != oshape:
+            raise ValueError("conv2d: residual2 needs residual and the output shape")
+        _check4(residual2, "conv2d residual2")
+        p.residual2 = residual2.data_ptr()
+        p.res2_batch_stride = _bs(residual2)
+        p.res2_chan_stride = _cs(residual2)
+    check(_lib.load().dvc_conv2d(C.byref(p), _stream()), "dvc_conv2d")
+    return out
+
+
+def flow_warp(src: Tensor, flow: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    n, c, h, w = src.shape
+    if tuple(flow.shape) != (n, 2, h, w):
+        raise ValueError(f"flow_warp: flow shape {tuple(flow.shape)} != {(n, 2, h, w)}")
+    if out is None:
+        out = torch.empty_like(src, memory_format=torch.contiguous_format)
+    check(_lib.load().dvc_flow_warp(C.byref(_src(src)), C.byref(_src(flow, "flow")), C.byref(_dst(out)),
+                                    n, h, w, _stream()), "dvc_flow_warp")
+    return out
+
+
+def avg_pool2(x: Tensor, scale: float = 1.0) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_avg_pool2(C.byref(_src(x)), C.byref(_dst(out)), n, h, w, float(scale), _stream()),
+          "dvc_avg_pool2")
+    return out
+
+
+def max_pool2(x: Tensor) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_max_pool2(C.byref(_src(x)), C.byref(_dst(out)), n, h, w, _stream()), "dvc_max_pool2")
+    return out
+
+
+def bilinear_up2(x: Tensor, scale: float = 1.0) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_bilinear_up2(C.byref(_src(x)), C.byref(_dst(out)), n, h, w, float(scale), _stream()),
+          "dvc_bilinear_up2")
+    return out
+
+
+def spynet_level_input(im1: Tensor, im2: Tensor, flow_prev: Optional[Tensor]) -> Tensor:
+    n, _, h, w = im1.shape
+    out = torch.empty((n, 8, h, w), dtype=torch.float32, device=im1.device)
+    fp = C.byref(_src(flow_prev, "flow_prev")) if flow_prev is not None else None
+    check(_lib.load().dvc_spynet_level_input(C.byref(_src(im1, "im1")), C.byref(_src(im2, "im2")), fp,
+                                             C.byref(_dst(out)), n, h, w, _stream()), "dvc_spynet_level_input")
+    return out
+
+
+def se_gate(x: Tensor, fc1: Tensor, fc2: Tensor) -> Tensor:
+    """sigmoid(fc2 @ relu(fc1 @ mean_hw(x))) -> (N*C,) gate."""
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    partial = torch.empty(lib.dvc_se_scratch_floats(n, c), dtype=torch.float32, device=x.device)
+    gate = torch.empty(n * c, dtype=torch.float32, device=x.device)
+    check(lib.dvc_se_gate(C.byref(_src(x)), n, h, w, fc1.data_ptr(), fc2.data_ptr(), fc1.size(0),
+                          partial.data_ptr(), gate.data_ptr(), _stream()), "dvc_se_gate")
+    return gate
+
+
+def copy_into(src: Tensor, out: Tensor) -> Tensor:
+    n, c, h, w = src.shape
+    if tuple(out.shape) != tuple(src.shape):
+        raise ValueError("copy_into: shape mismatch")
+    check(_lib.load().dvc_copy(C.byref(_src(src)), C.byref(_dst(out)), n, h, w, _stream()), "dvc_copy")
+    return out
+
+
+def clamp(x: Tensor, lo: float, hi: float) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_clamp(C.byref(_src(x)), C.byref(_dst(out)), n, h, w, float(lo), float(hi), _stream()),
+          "dvc_clamp")
+    return out
+
+
+def eb_forward(z: Tensor, packed: Tensor, medians: Tensor, noise: Optional[Tensor] = None,
+               want_likelihood=True, want_symbols=False):
+    """-> (z_hat, likelihood | None, symbols | None)"""
+    n, c, h, w = z.shape
+    z_hat = torch.empty((n, c, h, w), dtype=torch.float32, device=z.device)
+    lik = torch.empty_like(z_hat) if want_likelihood else None
+    sym = torch.empty((n, c, h, w), dtype=torch.int32, device=z.device) if want_symbols else None
+    if noise is not None and not (noise.is_contiguous() and tuple(noise.shape) == (n, c, h, w)):
+        raise ValueError("eb_forward: noise must be contiguous and shaped like z")
+    check(_lib.load().dvc_eb_forward(C.byref(_src(z, "z")), _ptr(noise), packed.data_ptr(), medians.data_ptr(),
+                                     C.byref(_dst(z_hat)), C.byref(_dst(lik) if lik is not None else _null_dst()),
+                                     _ptr(sym), n, h, w, _stream()), "dvc_eb_forward")
+    return z_hat, lik, sym
+
+
+def eb_dequantize(symbols: Tensor, medians: Tensor) -> Tensor:
+    n, c, h, w = symbols.shape
+    z_hat = torch.empty((n, c, h, w), dtype=torch.float32, device=symbols.device)
+    check(_lib.load().dvc_eb_dequantize(symbols.data_ptr(), medians.data_ptr(), C.byref(_dst(z_hat)), n, c, h, w,
+                                        _stream()), "dvc_eb_dequantize")
+    return z_hat
+
+
+def dual_prior_pass1(y: Tensor, means: Tensor, scales: Tensor) -> Tensor:
+    n, c, h, w = y.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=y.device)
+    check(_lib.load().dvc_dual_prior_pass1(C.byref(_src(y, "y")), C.byref(_src(means, "means")),
+                                           C.byref(_src(scales, "scales")), C.byref(_dst(out)), n, h, w, _stream()),
+          "dvc_dual_prior_pass1")
+    return out
+
+
+def dual_prior_pass2(y: Tensor, means: Tensor, scales: Tensor, spatial: Tensor, noise: Optional[Tensor] = None,
+                     want=("y_hat", "means_hat", "scales_hat", "likelihood"), scale_table: Optional[Tensor] = None):
+    """-> dict with the requested tensors; 'symbols' in `want` also yields 'indexes'
+    (both (2, N, C/2, h, w) int32: plane 0 = first-pass sites, plane 1 = second-pass sites)."""
+    n, c, h, w = y.shape
+    res = {}
+    dsts = {}
+    for k in ("y_hat", "means_hat", "scales_hat", "likelihood"):
+        if k in want:
+            res[k] = torch.empty((n, c, h, w), dtype=torch.float32, device=y.device)
+            dsts[k] = _dst(res[k])
+        else:
+            dsts[k] = _null_dst()
+    sym = idx = None
+    if "symbols" in want:
+        if scale_table is None:
+            raise ValueError("dual_prior_pass2: scale_table required for symbols/indexes")
+        sym = torch.empty((2, n, c // 2, h, w), dtype=torch.int32, device=y.device)
+        idx = torch.empty_like(sym)
+        res["symbols"], res["indexes"] = sym, idx
+    if noise is not None and not (noise.is_contiguous() and tuple(noise.shape) == (n, c, h, w)):
+        raise ValueError("dual_prior_pass2: noise must be contiguous and shaped like y")
+    check(_lib.load().dvc_dual_prior_pass2(
+        C.byref(_src(y, "y")), C.byref(_src(means, "means")), C.byref(_src(scales, "scales")),
+        C.byref(_src(spatial, "spatial")), _ptr(noise), C.byref(dsts["y_hat"]), C.byref(dsts["means_hat"]),
+        C.byref(dsts["scales_hat"]), C.byref(dsts["likelihood"]), _ptr(sym), _ptr(idx), _ptr(scale_table),
+        0 if scale_table is None else scale_table.numel(), n, h, w, _stream()), "dvc_dual_prior_pass2")
+    return res
+
+
+def dual_prior_dec_indexes(s: Tensor, plane: int, channels: int, scale_table: Tensor) -> Tensor:
+    n, _, h, w = s.shape
+    idx = torch.empty((n, channels // 2, h, w), dtype=torch.int32, device=s.device)
+    check(_lib.load().dvc_dual_prior_dec_indexes(C.byref(_src(s)), plane, idx.data_ptr(), scale_table.data_ptr(),
+                                                 scale_table.numel(), n, channels, h, w, _stream()),
+          "dvc_dual_prior_dec_indexes")
+    return idx
+
+
+def dual_prior_dec_apply(symbols: Tensor, m: Tensor, plane: int, channels: int,
+                         yhat1: Optional[Tensor] = None) -> Tensor:
+    n, _, h, w = m.shape
+    out = torch.empty((n, channels, h, w), dtype=torch.float32, device=m.device)
+    if symbols.dtype != torch.int32 or not symbols.is_contiguous() or symbols.numel() != n * (channels // 2) * h * w:
+        raise ValueError("dual_prior_dec_apply: symbols must be contiguous int32 (N, C/2, h, w)")
+    y1 = C.byref(_src(yhat1, "yhat1")) if yhat1 is not None else None
+    check(_lib.load().dvc_dual_prior_dec_apply(symbols.data_ptr(), C.byref(_src(m)), plane, y1, C.byref(_dst(out)),
+                                               n, channels, h, w, _stream()), "dvc_dual_prior_dec_apply")
+    return out
+
+
+def likelihood_bits(lik: Tensor) -> Tensor:
+    """(N,) tensor: sum over (C,H,W) of -log2(lik)."""
+    n, c, h, w = lik.shape
+    lib = _lib.load()
+    partial = torch.empty(lib.dvc_bits_scratch_floats(n), dtype=torch.float32, device=lik.device)
+    bits = torch.empty(n, dtype=torch.float32, device=lik.device)
+    check(lib.dvc_likelihood_bits(C.byref(_src(lik)), n, h, w, partial.data_ptr(), bits.data_ptr(), _stream()),
+          "dvc_likelihood_bits")
+    return bits
+
+
+def sq_err_sum(a: Tensor, b: Tensor) -> Tensor:
+    n, c, h, w = a.shape
+    if tuple(b.shape) != tuple(a.shape):
+        raise ValueError("sq_err_sum: shape mismatch")
+    lib = _lib.load()
+    partial = torch.empty(lib.dvc_bits_scratch_floats(n), dtype=torch.float32, device=a.device)
+    sse = torch.empty(n, dtype=torch.float32, device=a.device)
+    check(lib.dvc_sq_err_sum(C.byref(_src(a)), C.byref(_src(b)), n, h, w, partial.data_ptr(), sse.data_ptr(),
+                             _stream()), "dvc_sq_err_sum")
+    return sse

@@ -1,0 +1,226 @@
+/*
+ * dvc_hip.h -- C ABI of libdvc_hip.so: the MI355X (gfx950) kernels behind the
+ * DMC inter-frame path (motion estimation -> flow warp -> motion compensation
+ * -> contextual autoencoder -> entropy-model likelihoods / symbols) plus the
+ * host range coder.
+ *
+ * The reference (lumingzzz/DeepVideoCodec) exposes no FFI: its seam is the
+ * Python class models.DMC (dmc/models/__init__.py:1) and every operator below
+ * is a stock ATen / compressai call inside it.  Each entry point cites the
+ * reference lines whose arithmetic it replaces (paths relative to dmc/models/).
+ *
+ * Conventions
+ *  - All tensors are fp32 (symbols / indexes are int32), NCHW, rows contiguous
+ *    (element stride 1 along W, W along H).  Batch and channel strides are
+ *    explicit (in elements) so a tensor may be a channel-slice view of a larger
+ *    buffer.  The caller owns all memory; outputs are pre-allocated.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *    NULL = the null stream); no hidden synchronisation, no global state.
+ *  - Return value: 0 on success, negative DVC_E* on error; dvc_last_error()
+ *    returns a thread-local message for the last failing call on this thread.
+ */
+#ifndef DVC_HIP_H
+#define DVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVC_OK 0
+#define DVC_EINVAL (-1)   /* bad argument (shape / pointer / unsupported config) */
+#define DVC_EHIP (-2)     /* HIP runtime error (launch failed, no device ...) */
+#define DVC_ENOSPC (-3)   /* output buffer too small (host coder) */
+#define DVC_EFORMAT (-4)  /* malformed bitstream (host coder) */
+
+#define DVC_MAX_SRC 4
+
+/* A read-only NCHW fp32 operand (possibly one part of a channel concat). */
+typedef struct DvcSrc {
+  const float* ptr;      /* element (n=0, c=0, y=0, x=0) */
+  int64_t batch_stride;  /* elements between consecutive n */
+  int64_t chan_stride;   /* elements between consecutive c (>= H*W) */
+  int32_t channels;
+  int32_t _pad;
+} DvcSrc;
+
+/* A writable NCHW fp32 result. */
+typedef struct DvcDst {
+  float* ptr;
+  int64_t batch_stride;
+  int64_t chan_stride;
+} DvcDst;
+
+/*
+ * 2-D convolution, kernel 1/3/7, stride 1/2, zero padding k/2, with the
+ * element-wise neighbours of the reference graph folded in:
+ *
+ *   x   = concat(src[0..n_src-1], dim=C)               torch.cat call sites
+ *   x   = in_act ? leaky_relu(x, in_slope) : x         ResBlock.first_layer (layers.py:72,76)
+ *   t   = conv2d(x, weight[Cout,Cin,k,k], bias)        nn.Conv2d everywhere
+ *   t   = out_act ? leaky_relu(t, out_slope) : t       slope 0 == ReLU
+ *   t  += residual * (res_scale ? res_scale[n,c] : 1)  x + out (layers.py:81,114,142,168,295-297)
+ *   t  += residual2                                    context + context_out (video_model.py:62-64)
+ *   out = pixel_shuffle ? PixelShuffle(2)(t) : t       subpel_conv* (layers.py:45-56)
+ *
+ * With pixel_shuffle, `out`, `residual` and `res_scale` are laid out for the
+ * shuffled tensor (Cout/4 channels, 2H x 2W).
+ */
+typedef struct DvcConv2d {
+  DvcSrc src[DVC_MAX_SRC];
+  int32_t n_src;
+  int32_t batch, in_h, in_w;       /* input spatial size (all sources) */
+  const float* weight;             /* [Cout][Cin][k][k], Cin = sum(src.channels) */
+  const float* bias;               /* [Cout] or NULL */
+  int32_t out_channels;            /* Cout of the convolution (before shuffle) */
+  int32_t ksize;                   /* 1, 3 or 7 */
+  int32_t stride;                  /* 1 or 2 */
+  int32_t in_act, out_act;         /* 0 / 1 */
+  float in_slope, out_slope;
+  int32_t pixel_shuffle;           /* 0 or 1 (factor 2) */
+  DvcDst out;
+  const float* residual;           /* NULL or tensor in output layout */
+  int64_t res_batch_stride, res_chan_stride;
+  const float* res_scale;          /* NULL or [batch][out channels after shuffle] */
+  const float* residual2;          /* NULL or a second tensor in output layout (needs residual) */
+  int64_t res2_batch_stride, res2_chan_stride;
+} DvcConv2d;
+
+int dvc_conv2d(const DvcConv2d* p, void* stream);
+
+/* Backward bilinear warp, border clamp, flow in pixels (ch0 = x, ch1 = y):
+ * layers.py:175-198 (`torch_warp` = grid_sample(bilinear, border, align_corners=True)). */
+int dvc_flow_warp(const DvcSrc* src, const DvcSrc* flow, const DvcDst* out,
+                  int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* out = scale * mean of each 2x2 block.  avg_pool2d(2,2) (layers.py:250-251) with
+ * scale 1; bilineardownsacling(x)/2 (layers.py:201-206, video_model.py:499-500) with scale .5 */
+int dvc_avg_pool2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                  float scale, void* stream);
+
+/* MaxPool2d(2,2): layers.py:303,325,328. */
+int dvc_max_pool2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                  void* stream);
+
+/* out = scale * bilinear x2 upsample (align_corners=False): layers.py:209-214,257. */
+int dvc_bilinear_up2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                     float scale, void* stream);
+
+/* One SpyNet level's input (layers.py:257-262), fused:
+ *   flow_up = 2 * up2(flow_prev)   (flow_prev NULL => zeros)
+ *   out[:,0:3] = im1, out[:,3:6] = warp(im2, flow_up), out[:,6:8] = flow_up
+ * h, w are the level's (output) size; flow_prev is (h/2, w/2). */
+int dvc_spynet_level_input(const DvcSrc* im1, const DvcSrc* im2, const DvcSrc* flow_prev,
+                           const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* Squeeze-excite gate (layers.py:267-280): gate[n,c] = sigmoid(W2 relu(W1 mean_hw(x[n,c]))).
+ * fc1 [C/r][C], fc2 [C][C/r].  `partial` is caller scratch of >= dvc_se_scratch_floats() floats.
+ * Deterministic (fixed-order two-stage reduction, no float atomics). */
+int64_t dvc_se_scratch_floats(int32_t batch, int32_t channels);
+int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1,
+                const float* fc2, int32_t hidden, float* partial, float* gate, void* stream);
+
+/* Plain strided copy / elementwise helpers. */
+int dvc_copy(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream);
+int dvc_clamp(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+              float lo, float hi, void* stream);
+
+/*
+ * Factorized prior (compressai EntropyBottleneck as used at video_model.py:220-224,
+ * 392-396; parameters base_model.py:63): per-channel cumulative 1-3-3-3-3-1.
+ *   z_hat   = round(z - median[c]) + median[c]      (mode 0)   or   z + noise (mode 1, noise given)
+ *   lik     = max(|sigmoid(s*upper) - sigmoid(s*lower)|, 1e-9), logits at z_hat -/+ .5
+ *   symbols = int32 round(z - median[c])            (optional, may be NULL)
+ * matrices/biases/factors: the raw parameters packed per channel as
+ * [m0(3) b0(3) f0(3) | m1(9) b1(3) f1(3) | m2 .. | m3 .. | m4(3) b4(1)] = 58 floats. */
+#define DVC_EB_PARAMS_PER_CHANNEL 58
+int dvc_eb_forward(const DvcSrc* z, const float* noise, const float* packed_params,
+                   const float* medians, const DvcDst* z_hat, const DvcDst* likelihood,
+                   int32_t* symbols, int32_t batch, int32_t h, int32_t w, void* stream);
+/* z_hat = symbols + median[c] (EntropyBottleneck.decompress' dequantise, video_model.py:257). */
+int dvc_eb_dequantize(const int32_t* symbols, const float* medians, const DvcDst* z_hat,
+                      int32_t batch, int32_t channels, int32_t h, int32_t w, void* stream);
+
+/* Checkerboard dual prior, first pass (video_model.py:184-189 / 356-361):
+ * yhat1[:, :C/2] = (round(y0 - mu0) + mu0) on even sites, 0 elsewhere;
+ * yhat1[:, C/2:] = same for the second half on odd sites. */
+int dvc_dual_prior_pass1(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales,
+                         const DvcDst* yhat1, int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* Second pass + merge + Gaussian likelihood (video_model.py:192-216,232 and compressai
+ * GaussianConditional): `spatial` is the y_spatial_prior output (2C channels:
+ * mu0, sigma0, mu1, sigma1).  Outputs (any may have ptr NULL): y_hat, means_hat,
+ * scales_hat, likelihood (all C channels); noise (C ch, may be NULL) switches the
+ * likelihood input to y + noise (training-mode rate, video_model.py:232).
+ * compress-mode outputs (may be NULL): symbols[2][N][C/2][h][w], indexes same shape
+ * (video_model.py:209-214,248-249), scale_table[n_scales] device pointer. */
+int dvc_dual_prior_pass2(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales,
+                         const DvcSrc* spatial, const float* noise, const DvcDst* y_hat,
+                         const DvcDst* means_hat, const DvcDst* scales_hat,
+                         const DvcDst* likelihood, int32_t* symbols, int32_t* indexes,
+                         const float* scale_table, int32_t n_scales, int32_t batch, int32_t h,
+                         int32_t w, void* stream);
+
+/* Decoder side (video_model.py:268-289 / 443-464).
+ * step 0: indexes of plane 0 from hyper (means, scales).
+ * step 1: yhat1 from decoded plane-0 symbols.
+ * step 2: indexes of plane 1 from the spatial prior output.
+ * step 3: y_hat from yhat1 + decoded plane-1 symbols. */
+int dvc_dual_prior_dec_indexes(const DvcSrc* scales_or_spatial, int32_t plane, int32_t* indexes,
+                               const float* scale_table, int32_t n_scales, int32_t batch,
+                               int32_t channels, int32_t h, int32_t w, void* stream);
+int dvc_dual_prior_dec_apply(const int32_t* symbols, const DvcSrc* means_or_spatial, int32_t plane,
+                             const DvcSrc* yhat1_in, const DvcDst* out, int32_t batch,
+                             int32_t channels, int32_t h, int32_t w, void* stream);
+
+/* Stand-alone Gaussian conditional (compressai GaussianConditional.forward as called at
+ * video_model.py:232,405): outputs = round(x - mu) + mu (or x + noise when noise != NULL,
+ * noise contiguous like x); lik = max(Phi((.5-|o-mu|)/s) - Phi((-.5-|o-mu|)/s), 1e-9), s = max(scale,.11).
+ * means may be NULL (zero). */
+int dvc_gaussian_conditional(const DvcSrc* x, const DvcSrc* scales, const DvcSrc* means,
+                             const float* noise, const DvcDst* outputs, const DvcDst* likelihood,
+                             int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* GaussianConditional.build_indexes (video_model.py:248-249): index of the scale-table bin,
+ * idx = (n_scales-1) - #{k < n_scales-1 : max(scale,.11) <= table[k]}; indexes contiguous like scales. */
+int dvc_build_indexes(const DvcSrc* scales, int32_t* indexes, const float* scale_table,
+                      int32_t n_scales, int32_t batch, int32_t h, int32_t w, void* stream);
+
+/* bits[n] = sum over (c,h,w) of -log2(lik[n,...])  (dmc/train.py:83).  Deterministic
+ * two-stage wavefront-shuffle reduction; `partial` >= dvc_bits_scratch_floats() floats. */
+int64_t dvc_bits_scratch_floats(int32_t batch);
+int dvc_likelihood_bits(const DvcSrc* lik, int32_t batch, int32_t h, int32_t w, float* partial,
+                        float* bits, void* stream);
+
+/* sse[n] = sum (a-b)^2 over (c,h,w) (PSNR numerator, dmc/test.py:205). Same scratch rule. */
+int dvc_sq_err_sum(const DvcSrc* a, const DvcSrc* b, int32_t batch, int32_t h, int32_t w,
+                   float* partial, float* sse, void* stream);
+
+/*
+ * Host range coder (no GPU involved): restates compressai.ans
+ * RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as used at
+ * video_model.py:238-239,250-251,257,273,283.  64-bit-state rANS, 32-bit words,
+ * 16-bit CDF precision, 4-bit bypass escape.  cdfs is [n_cdfs][cdf_stride] int32.
+ * dvc_rans_encode returns the number of bytes written (>= 8) or a negative DVC_E*.
+ */
+int64_t dvc_rans_encode(const int32_t* symbols, const int32_t* indexes, int64_t n,
+                        const int32_t* cdfs, int32_t n_cdfs, int32_t cdf_stride,
+                        const int32_t* cdf_sizes, const int32_t* offsets, uint8_t* out,
+                        int64_t out_capacity);
+int dvc_rans_decode(const uint8_t* data, int64_t n_bytes, const int32_t* indexes, int64_t n,
+                    const int32_t* cdfs, int32_t n_cdfs, int32_t cdf_stride,
+                    const int32_t* cdf_sizes, const int32_t* offsets, int32_t* symbols_out);
+/* Integer CDF of total 2^precision with every frequency >= 1 (compressai _CXX
+ * pmf_to_quantized_cdf).  cdf_out has n_pmf + 1 entries. */
+int dvc_pmf_to_quantized_cdf(const float* pmf, int32_t n_pmf, int32_t precision, int32_t* cdf_out);
+
+const char* dvc_last_error(void);
+/* Library / device introspection: number of visible HIP devices (<0 on error). */
+int dvc_device_count(void);
+const char* dvc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVC_HIP_H */

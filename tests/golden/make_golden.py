@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python files.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+What is imported from the reference:
+  * dmc/models/layers.py and dmc/models/utils.py load as they are (pure torch).
+  * dmc/models/video_model.py / base_model.py import the third-party package
+    `compressai`, which is absent and not installable here.  Before importing the
+    reference package, this script registers oracle.entropy_oracle as
+    `compressai.entropy_models`; the reference's graph code then runs unmodified,
+    with this repository's restatement of the entropy arithmetic underneath.
+    => wiring (channel order, concat order, checkerboard parity, dpb flow) is pinned
+       by the reference; entropy arithmetic is "parity unpinned".
+
+Only data (inputs, seeds, expected outputs) is written; no reference source travels.
+Weights are not stored: they are regenerated from the seed by
+deepvideocodec_amd.testing.seeded_state_dict and loaded into the reference model.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/dmc"
+
+from oracle import entropy_oracle  # noqa: E402
+from deepvideocodec_amd.testing import random_gop, seeded_state_dict, synthetic_gop  # noqa: E402
+
+
+def import_reference():
+    pkg = types.ModuleType("compressai")
+    pkg.__path__ = []
+    pkg.entropy_models = entropy_oracle
+    sys.modules["compressai"] = pkg
+    sys.modules["compressai.entropy_models"] = entropy_oracle
+    sys.path.insert(0, REF)
+    import models  # the reference package
+    from models import layers, utils, video_model
+    return models, layers, utils, video_model
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    models, layers, utils, video_model = import_reference()
+
+    # ---------------- op-level fixtures straight from layers.py / utils.py
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    feat = torch.randn(2, 5, 24, 40, generator=g)
+    flow = torch.randn(2, 2, 24, 40, generator=g) * 3.0
+    flow[0, :, 0, 0] = torch.tensor([-50.0, 60.0])   # far outside: exercises the border clamp
+    flow[1, :, -1, -1] = torch.tensor([70.0, -80.0])
+    out["warp_feat"], out["warp_flow"] = feat, flow
+    out["warp_out"] = layers.flow_warp(feat, flow)
+    layers.backward_grid[-1].clear()
+    x = torch.randn(2, 2, 12, 20, generator=g)
+    out["resample_in"] = x
+    out["up2_out"] = layers.bilinearupsacling(x)
+    out["down2_out"] = layers.bilineardownsacling(x)
+    q = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 0.49999, 3.2, -7.7])
+    out["ste_in"], out["ste_out"] = q, utils.quantize_ste(q)
+    np.savez_compressed(os.path.join(HERE, "ops_layers.npz"), **to_np(out))
+    print("ops_layers.npz written")
+
+    # ---------------- whole-model fixtures from the reference DMC graph
+    sd = seeded_state_dict(seed=0)
+    net = models.DMC()
+    missing = net.load_state_dict(sd, strict=True)
+    net.eval()
+    net.update(force=True)
+    import json
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in models.DMC().state_dict().items()}, f, indent=0, sort_keys=True)
+    print("state_dict_keys.json written")
+
+    with torch.no_grad():
+        # (a) SpyNet + motion encoder/decoder + UNet blocks on a 64x64 pair
+        frames = synthetic_gop(3, 64, 64, seed=11)
+        blk = {"x0": frames[0], "x1": frames[1]}
+        mv = net.optic_flow(frames[1], frames[0])
+        blk["spynet_mv"] = mv
+        y_mv = net.motion_encoder(mv)
+        blk["motion_enc"] = y_mv
+        blk["motion_dec"] = net.motion_decoder(y_mv)
+        f64 = torch.randn(1, 64, 32, 32, generator=g) * 0.5
+        blk["unet_in"] = f64
+        blk["unet_out"] = net.recon_generation_net.unet_1(f64)
+        ctx = [torch.randn(1, 64, 32 >> i, 32 >> i, generator=g) * 0.5 for i in range(3)]
+        fo = net.context_fusion_net(*ctx)
+        for i in range(3):
+            blk[f"fusion_in{i}"] = ctx[i]
+            blk[f"fusion_out{i}"] = fo[i]
+        np.savez_compressed(os.path.join(HERE, "blocks_64.npz"), **to_np(blk))
+        print("blocks_64.npz written")
+
+        # (b) forward() over a 4-frame GOP at 64x64 (three P frames: covers feature_adaptor_I
+        #     and feature_adaptor_P, y_ref None and not None)
+        for tag, frames in (("synthetic", synthetic_gop(4, 64, 64, seed=3)), ("rand", random_gop(4, 64, 64, seed=4))):
+            res = net(frames)
+            fw = {}
+            for i, f in enumerate(frames):
+                fw[f"frame{i}"] = f
+            for i, (xh, lk) in enumerate(zip(res["x_hat"], res["likelihoods"])):
+                fw[f"x_hat{i}"] = xh
+                for a in ("motion", "frame"):
+                    for b in ("y", "z"):
+                        fw[f"lik{i}_{a}_{b}"] = lk[a][b]
+            np.savez_compressed(os.path.join(HERE, f"forward_64_{tag}.npz"), **to_np(fw))
+            print(f"forward_64_{tag}.npz written")
+
+        # (c) encode_inter / decode_inter loop (dmc/test.py:186-195) on 3 frames at 64x64
+        frames = synthetic_gop(3, 64, 64, seed=5)
+        dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+        codec = {"frame0": frames[0]}
+        for i in (1, 2):
+            enc = net.encode_inter(frames[i], dpb)
+            rec, info = net.decode_inter(enc["strings"], enc["shape"], dpb)
+            rec = rec.clamp(0, 1)
+            dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+                   "y_mv_ref": info["y_mv_ref"]}
+            codec[f"frame{i}"] = frames[i]
+            codec[f"rec{i}"] = rec
+            codec[f"y_ref{i}"] = info["y_ref"]
+            codec[f"y_mv_ref{i}"] = info["y_mv_ref"]
+            for key in ("motion", "frame"):
+                for j, s in enumerate(enc["strings"][key]):
+                    codec[f"bytes{i}_{key}_{j}"] = np.frombuffer(s[0], dtype=np.uint8)
+                codec[f"shape{i}_{key}"] = np.asarray(tuple(enc["shape"][key]))
+        np.savez_compressed(os.path.join(HERE, "codec_64.npz"), **to_np(codec))
+        print("codec_64.npz written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, and its host entry points (range coder, CDF quantiser) agree with the oracle.
+No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from deepvideocodec_amd import _lib
+from oracle import entropy_oracle, rans_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "dvc_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dvc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/dvc_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert b"gfx950" in lib.dvc_version()
+
+
+def test_struct_layout_matches_header():
+    # sizes the C compiler gives the same structs (checked against offsetof in the library build)
+    assert ctypes.sizeof(_lib.DvcSrc) == 32
+    assert ctypes.sizeof(_lib.DvcDst) == 24
+    assert ctypes.sizeof(_lib.DvcConv2d) % 8 == 0
+
+
+def test_invalid_arguments_are_reported_not_crashed():
+    lib = _lib.load()
+    p = _lib.DvcConv2d()
+    p.n_src = 0
+    rc = lib.dvc_conv2d(ctypes.byref(p), None)
+    assert rc == -1
+    assert "n_src" in _lib.last_error()
+    with pytest.raises(_lib.DvcError):
+        _lib.check(rc, "dvc_conv2d")
+
+
+def _tables(seed=0, n_cdf=5):
+    rng = np.random.default_rng(seed)
+    rows, sizes, offs = [], [], []
+    for i in range(n_cdf):
+        n = int(rng.integers(3, 40))
+        pmf = rng.random(n).astype(np.float32) ** 3 + 1e-6
+        pmf = pmf / pmf.sum() * 0.999
+        tail = np.float32(0.001)
+        cdf = entropy_oracle.pmf_to_quantized_cdf(list(map(float, pmf)) + [float(tail)], 16)
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-(n // 2))
+    stride = max(sizes)
+    tab = np.zeros((n_cdf, stride), dtype=np.int32)
+    for i, r in enumerate(rows):
+        tab[i, :len(r)] = r
+    return tab, np.asarray(sizes, np.int32), np.asarray(offs, np.int32)
+
+
+def test_pmf_to_quantized_cdf_matches_oracle():
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 64, 300):
+        pmf = (rng.random(n).astype(np.float32) ** 4)
+        if n > 1:
+            pmf[rng.integers(0, n)] = 0.0      # forces the "steal a count" branch
+        pmf = (pmf / max(pmf.sum(), 1e-9)).astype(np.float32)
+        want = entropy_oracle.pmf_to_quantized_cdf([float(v) for v in pmf], 16)
+        got = np.zeros(n + 1, dtype=np.int32)
+        rc = lib.dvc_pmf_to_quantized_cdf(pmf.ctypes.data, n, 16, got.ctypes.data)
+        assert rc == 0, _lib.last_error()
+        assert got.tolist() == want
+        assert got[0] == 0 and got[-1] == 65536 and np.all(np.diff(got) >= 1)
+
+
+@pytest.mark.parametrize("n_sym", [0, 1, 17, 5000])
+def test_rans_matches_oracle_and_round_trips(n_sym):
+    from deepvideocodec_amd.models.entropy_models import _CoderTables
+    tab, sizes, offs = _tables()
+    rng = np.random.default_rng(n_sym)
+    idx = rng.integers(0, tab.shape[0], n_sym).astype(np.int32)
+    # mostly in-range symbols plus escapes on both sides (bypass coding)
+    sym = np.array([int(rng.integers(offs[i] - 3, offs[i] + sizes[i] + 3)) for i in idx], dtype=np.int32)
+    if n_sym >= 17:
+        sym[3] = offs[idx[3]] - 70000      # multi-nibble escape, > 15 nibbles path of the count
+        sym[5] = offs[idx[5]] + 1000000
+    ct = _CoderTables(torch.from_numpy(tab), torch.from_numpy(sizes), torch.from_numpy(offs))
+    data = ct.encode(sym, idx)
+    want = rans_oracle.encode_with_indexes(sym.tolist(), idx.tolist(), tab.tolist(), sizes.tolist(), offs.tolist())
+    assert data == want
+    assert ct.decode(data, idx).tolist() == sym.tolist()
+    assert rans_oracle.decode_with_indexes(data, idx.tolist(), tab.tolist(), sizes.tolist(), offs.tolist()) == sym.tolist()
+
+
+def test_rans_decode_rejects_truncated_stream():
+    from deepvideocodec_amd.models.entropy_models import _CoderTables
+    tab, sizes, offs = _tables()
+    idx = np.zeros(4000, np.int32)
+    sym = np.random.default_rng(0).integers(offs[0], offs[0] + sizes[0] - 2, 4000).astype(np.int32)
+    ct = _CoderTables(torch.from_numpy(tab), torch.from_numpy(sizes), torch.from_numpy(offs))
+    data = ct.encode(sym, idx)
+    with pytest.raises(_lib.DvcError):
+        ct.decode(data[:7], idx)
+    with pytest.raises(_lib.DvcError):
+        ct.decode(data[:len(data) // 2 // 4 * 4], idx)
+
+
+def test_ops_refuse_cpu_tensors():
+    from deepvideocodec_amd import ops
+    with pytest.raises(_lib.DvcError):
+        ops.flow_warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))

@@ -1,0 +1,160 @@
+"""Whole-path parity on the GPU: the product DMC (HIP kernels through the C ABI) against
+(1) the fixtures captured from the reference's own graph and (2) the CPU oracle, with the
+north-star tolerances: |dPSNR| <= 1e-3 dB and |dbpp| <= 1e-4 on the same inputs; plus
+size-independent properties at the full 1088x1920 size."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PSNR_TOL = 1e-3
+BPP_TOL = 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def psnr(x, rec):
+    return -10.0 * math.log10(torch.mean((x.double() - rec.double()) ** 2).item())
+
+
+def bits(lik):
+    return -torch.log2(lik.double()).sum().item()
+
+
+@pytest.mark.parametrize("tag", ["synthetic", "rand"])
+def test_forward_matches_reference_fixture(gpu_net, tag):
+    g = load_golden(f"forward_64_{tag}.npz")
+    frames = [T(g[f"frame{i}"]) for i in range(4)]
+    res = gpu_net([f.cuda() for f in frames])
+    assert set(res) == {"x_hat", "likelihoods"} and len(res["x_hat"]) == 3
+    n_pix = 64 * 64
+    for i in range(3):
+        ref = T(g[f"x_hat{i}"])
+        got = res["x_hat"][i].cpu()
+        assert abs(psnr(frames[i + 1], got) - psnr(frames[i + 1], ref)) <= PSNR_TOL, i
+        assert (got - ref).abs().max().item() < 5e-4, i
+        d_bits = 0.0
+        for a in ("motion", "frame"):
+            for b in ("y", "z"):
+                lk = res["likelihoods"][i][a][b]
+                assert tuple(lk.shape) == tuple(g[f"lik{i}_{a}_{b}"].shape)
+                d_bits += bits(lk.cpu()) - bits(T(g[f"lik{i}_{a}_{b}"]))
+        assert abs(d_bits) / n_pix <= BPP_TOL, (i, d_bits)
+
+
+def test_codec_loop_matches_reference_fixture(gpu_net):
+    """encode_inter -> decode_inter -> clamp -> dpb update (dmc/test.py:186-195)."""
+    g = load_golden("codec_64.npz")
+    dpb = {"x_ref": T(g["frame0"]).cuda(), "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    total_ref = total_got = 0
+    for i in (1, 2):
+        x = T(g[f"frame{i}"])
+        enc = gpu_net.encode_inter(x.cuda(), dpb)
+        assert set(enc) == {"strings", "shape"}
+        for key in ("motion", "frame"):
+            assert tuple(enc["shape"][key]) == tuple(g[f"shape{i}_{key}"])
+            assert len(enc["strings"][key]) == 3
+            for j in range(3):
+                s = enc["strings"][key][j]
+                assert isinstance(s, list) and len(s) == 1 and isinstance(s[0], bytes)
+                total_got += len(s[0])
+                total_ref += g[f"bytes{i}_{key}_{j}"].size
+                # identical symbols => identical bytes (integer work is bit-exact)
+                assert s[0] == g[f"bytes{i}_{key}_{j}"].tobytes(), (i, key, j)
+        rec, info = gpu_net.decode_inter(enc["strings"], enc["shape"], dpb)
+        assert set(info) == {"x_ref", "feature_ref", "y_ref", "y_mv_ref"}
+        rec = rec.clamp(0, 1)
+        ref = T(g[f"rec{i}"])
+        assert abs(psnr(x, rec.cpu()) - psnr(x, ref)) <= PSNR_TOL
+        assert (info["y_ref"].cpu() - T(g[f"y_ref{i}"])).abs().max().item() < 1e-4
+        assert (info["y_mv_ref"].cpu() - T(g[f"y_mv_ref{i}"])).abs().max().item() < 1e-4
+        dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+               "y_mv_ref": info["y_mv_ref"]}
+    assert total_got == total_ref
+
+
+def test_forward_vs_oracle_128_batch2(gpu_net, seeded_sd, oracle_entropy):
+    """A different size and batch 2, against the oracle run on the CPU in the same test."""
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = synthetic_gop(3, 128, 192, seed=7, batch=2)
+    with torch.no_grad():
+        want = O.forward(seeded_sd, oracle_entropy, frames)
+    got = gpu_net([f.cuda() for f in frames])
+    n_pix = 128 * 192
+    for i in range(2):
+        for b in range(2):
+            pw = psnr(frames[i + 1][b], want["x_hat"][i][b])
+            pg = psnr(frames[i + 1][b], got["x_hat"][i][b].cpu())
+            assert abs(pw - pg) <= PSNR_TOL, (i, b, pw, pg)
+        bw = O.likelihood_bpp([want["likelihoods"][i]], n_pix)
+        bg = O.likelihood_bpp([{k: {f: t.cpu() for f, t in v.items()} for k, v in got["likelihoods"][i].items()}], n_pix)
+        assert (bw - bg).abs().max().item() <= BPP_TOL, (i, bw, bg)
+
+
+def test_decode_reproduces_encoder_state(gpu_net):
+    """The decoder rebuilds exactly the latents the encoder quantised (bit-exact), and
+    decode(encode(x)) equals forward()'s reconstruction in eval mode."""
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = [f.cuda() for f in synthetic_gop(2, 128, 128, seed=9)]
+    dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    fwd = gpu_net(frames)
+    enc = gpu_net.encode_inter(frames[1], dpb)
+    rec, info = gpu_net.decode_inter(enc["strings"], enc["shape"], dpb)
+    assert torch.equal(rec, fwd["x_hat"][0])
+    x_rec, lik, ctx = gpu_net.forward_inter(frames[1], dpb)
+    assert torch.equal(info["y_ref"], ctx["y_ref"]) and torch.equal(info["y_mv_ref"], ctx["y_mv_ref"])
+    assert torch.equal(info["feature_ref"], ctx["feature_ref"])
+    # actual bytes are close to the likelihood estimate
+    est = sum(bits(t.cpu()) for v in lik.values() for t in v.values())
+    act = 8 * sum(len(s[0]) for v in enc["strings"].values() for s in v)
+    assert act <= 1.05 * est + 6 * 64 and act >= 0.95 * est - 64
+
+
+def test_motion_pretrain_and_training_mode(gpu_net):
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = [f.cuda() for f in synthetic_gop(3, 64, 64, seed=13)]
+    out = gpu_net(frames, motion_pretrain=True)
+    assert len(out["x_hat"]) == 2 and set(out["likelihoods"][0]) == {"motion"}
+    gpu_net.train()
+    try:
+        torch.manual_seed(0)
+        a = gpu_net(frames)
+        torch.manual_seed(1)
+        b = gpu_net(frames)
+    finally:
+        gpu_net.eval()
+    # decoder path is noise-free (round-STE), the rate is computed on noisy latents
+    assert torch.equal(a["x_hat"][0], b["x_hat"][0])
+    assert not torch.equal(a["likelihoods"][0]["frame"]["y"], b["likelihoods"][0]["frame"]["y"])
+
+
+def test_full_size_round_trip_1080p(gpu_net):
+    """BASELINE config 2 size (1080p padded to 1088x1920), two P frames: size-independent
+    properties -- decode(encode(x)) == forward(x), the dpb recurrence stays consistent, the
+    coded size tracks the likelihood estimate, reconstruction is finite."""
+    from deepvideocodec_amd.testing import pad_to_multiple, synthetic_gop
+    frames = [pad_to_multiple(f, 64).cuda() for f in synthetic_gop(3, 1080, 1920, seed=1)]
+    assert tuple(frames[0].shape) == (1, 3, 1088, 1920)
+    dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    fwd = gpu_net(frames)
+    n_pix = 1080 * 1920
+    for i in (1, 2):
+        enc = gpu_net.encode_inter(frames[i], dpb)
+        assert tuple(enc["shape"]["motion"]) == (17, 30) and tuple(enc["shape"]["frame"]) == (17, 30)
+        rec, info = gpu_net.decode_inter(enc["strings"], enc["shape"], dpb)
+        assert torch.isfinite(rec).all()
+        assert torch.equal(rec, fwd["x_hat"][i - 1])
+        est = sum(bits(t.cpu()) for v in fwd["likelihoods"][i - 1].values() for t in v.values())
+        act = 8 * sum(len(s[0]) for v in enc["strings"].values() for s in v)
+        assert abs(act - est) / n_pix < 0.02 * est / n_pix + 1e-3
+        # forward() chains on the un-clamped reconstruction (reference: video_model.py:544-549)
+        dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+               "y_mv_ref": info["y_mv_ref"]}
