@@ -20,10 +20,38 @@ def _gen(seed: int, name: str) -> torch.Generator:
     return g
 
 
-def seeded_state_dict(seed: int = 0, ch_mv: int = 64, N: int = 64, M: int = 96) -> Dict[str, torch.Tensor]:
+def _calibration(seed: int):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"calibration_seed{seed}.json")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"no calibration gains for seed {seed} ({path}); "
+                                "generate them with tests/golden/make_calibration.py or pass calibrated=False")
+    with open(path) as f:
+        return json.load(f)
+
+
+def seeded_state_dict(seed: int = 0, ch_mv: int = 64, N: int = 64, M: int = 96,
+                      calibrated: bool = True) -> Dict[str, torch.Tensor]:
     """A full DMC state dict (reference key names) with the reference's init distributions
     (Xavier-normal gain sqrt(2) conv weights) drawn from per-tensor seeded generators, plus
-    mildly perturbed biases / factorized-prior parameters so that every parameter matters."""
+    mildly perturbed biases / factorized-prior parameters so that every parameter matters.
+
+    calibrated=True additionally applies the stored per-layer gains (data/calibration_seed*.json)
+    that keep activations O(1) like a trained codec's, so that PSNR / bpp are meaningful;
+    calibrated=False is the raw reference-style init (activations grow to ~1e4)."""
+    sd = _raw_seeded_state_dict(seed, ch_mv, N, M)
+    if calibrated:
+        cal = _calibration(seed)
+        for name, g in cal["gain"].items():
+            sd[name + ".weight"] = sd[name + ".weight"] * g
+            sd[name + ".bias"] = sd[name + ".bias"] * g
+        for name, shift in cal["bias_shift"].items():
+            sd[name + ".bias"] = sd[name + ".bias"] + torch.tensor(shift)
+    return sd
+
+
+def _raw_seeded_state_dict(seed: int, ch_mv: int, N: int, M: int) -> Dict[str, torch.Tensor]:
     from .models import DMC
 
     net = DMC(ch_mv, N, M)

@@ -40,7 +40,7 @@ def test_forward_matches_reference_fixture(gpu_net, tag):
         ref = T(g[f"x_hat{i}"])
         got = res["x_hat"][i].cpu()
         assert abs(psnr(frames[i + 1], got) - psnr(frames[i + 1], ref)) <= PSNR_TOL, i
-        assert (got - ref).abs().max().item() < 5e-4, i
+        assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), i
         d_bits = 0.0
         for a in ("motion", "frame"):
             for b in ("y", "z"):
