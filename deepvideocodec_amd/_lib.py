@@ -31,7 +31,7 @@ class DvcConv2d(C.Structure):
         ("src", DvcSrc * DVC_MAX_SRC),
         ("n_src", C.c_int32),
         ("batch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
-        ("weight", C.c_void_p),
+        ("weight_packed", C.c_void_p),
         ("bias", C.c_void_p),
         ("out_channels", C.c_int32),
         ("ksize", C.c_int32),
@@ -56,6 +56,8 @@ _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 # name -> (restype, argtypes); must list every symbol include/dvc_hip.h declares.
 SIGNATURES = {
     "dvc_conv2d": (C.c_int, [C.POINTER(DvcConv2d), _P]),
+    "dvc_conv2d_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
+    "dvc_conv2d_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
     "dvc_flow_warp": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_avg_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
     "dvc_max_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),

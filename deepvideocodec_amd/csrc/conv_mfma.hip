@@ -12,8 +12,15 @@
 // The result is bit-for-bit a k-ordered fmaf chain (ci-pair major, tap minor,
 // lower channel of the pair first).
 //
+// Pipeline.  The K loop walks the input channels in chunks of CK, with two LDS
+// buffers for the input tile and for the weight slab.  While the MFMAs of chunk k
+// run, chunk k+1 is in flight: its weight slab goes global -> LDS directly
+// (global_load_lds, 16 B per lane, no registers; weights are pre-packed so a slab
+// is one contiguous range), its input halo tile goes into registers and is written
+// to the other LDS buffer after the MFMA phase.  One barrier per chunk.
+//
 // Fused around the MFMA loop: channel concat of up to 4 sources and LeakyReLU on
-// the input while staging; bias, LeakyReLU/ReLU, scaled residual add and the
+// the input while staging; bias, LeakyReLU/ReLU, (scaled) residual adds and the
 // PixelShuffle(2) scatter in the epilogue.
 #include "dvc_common.h"
 
@@ -26,7 +33,7 @@ struct ConvArgs {
   int n_src;
   int cin, h, w;         // input
   int cout, ho, wo;      // conv output (before shuffle)
-  const float* weight;
+  const float* wpacked;  // [cout block][chunk][slab], see pack_weight_kernel
   const float* bias;
   float* out;
   long long obs, ocs;
@@ -41,34 +48,139 @@ struct ConvArgs {
   int tiles_x;
 };
 
-template <int KS, int S>
-struct ChunkOf {  // input channels staged per K-chunk (even)
-  static constexpr int value = (KS == 7) ? 2 : (KS == 1) ? 16 : (S == 2 ? 4 : 8);
+// input channels staged per K-chunk (even)
+constexpr int chunk_of(int ks, int s) { return ks == 7 ? 2 : ks == 1 ? 16 : (s == 2 ? 4 : 8); }
+constexpr int cout_block_of(int cout) { return cout > 32 ? 64 : 32; }
+// floats per packed weight slab: CK * k*k rows of CB output channels, padded to whole 1 KiB
+// pieces (one global_load_lds wave-instruction moves 64 lanes x 16 B)
+constexpr int slab_floats(int ks, int s, int cb) { return (chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
+
+// OIHW -> [cout block][chunk][row = (ci - c0) * taps + tap][co - cb0], zero filled past Cin / Cout.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* packed, int cout, int cin, int ks,
+                                                          int ck, int cb, int slab, int nchunks, long long total) {
+  const int taps = ks * ks;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i % slab);
+    const long long t = i / slab;
+    const int chunk = (int)(t % nchunks), blk = (int)(t / nchunks);
+    const int row = e / cb, col = e - row * cb;
+    const int ci = chunk * ck + row / taps, tap = row % taps;
+    const int co = blk * cb + col;
+    float v = 0.f;
+    if (row < ck * taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
+    packed[i] = v;
+  }
+}
+
+template <int MT, int NT>
+constexpr int min_waves_per_simd() { return 2; }
+
+template <int KS, int S, int MT, int NT>
+struct Geo {
+  static constexpr int CK = chunk_of(KS, S);
+  static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
+  static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
+  static constexpr int IH = (TH - 1) * SL + KS;
+  static constexpr int IW = (TW - 1) * SL + KS;
+  static constexpr int CHS = IH * IW;            // floats per staged channel
+  static constexpr int TAPS = KS * KS;
+  static constexpr int KCH = CK * TAPS;          // k values per chunk
+  static constexpr int SLAB = slab_floats(KS, S, CB);
+  static constexpr int IN_BUF = (CK * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
+  static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
+  static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
+  static constexpr int LDS_BYTES = (2 * IN_BUF + 2 * SLAB) * 4;
 };
 
 template <int KS, int S, int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a) {
-  constexpr int CK = ChunkOf<KS, S>::value;
-  constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
-  constexpr int SL = (KS == 1) ? 1 : S;  // pixel stride inside the LDS tile
-  constexpr int IH = (TH - 1) * SL + KS;
-  constexpr int IW = (TW - 1) * SL + KS;
-  constexpr int IWP = IW;
-  constexpr int CHS = IH * IWP;          // floats per staged channel
-  constexpr int TAPS = KS * KS;
-  constexpr int KCH = CK * TAPS;         // k values per chunk
-  constexpr int CBP = CB + 1;            // padded cout pitch of the weight image
+__global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
+  using G = Geo<KS, S, MT, NT>;
+  constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW;
+  constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
 
-  __shared__ float in_s[CK * CHS];
-  __shared__ float w_s[KCH * CBP];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const w_s = lds;                // [2][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
+  float* const in_s = lds + 2 * SLAB;    // [2][IN_BUF]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = blockIdx.x;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int cb0 = blockIdx.y * CB;
   const int n = blockIdx.z;
+  const int nchunks = (a.cin + CK - 1) / CK;
+
+  // ---- per-thread staging descriptors (identical for every channel and chunk)
+  const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
+  const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
+  int in_goff[IN_PT];        // offset inside a channel plane, 0 when the element is padding
+  unsigned in_okmask = 0;    // bit j: element j is inside the image
+#pragma unroll
+  for (int j = 0; j < IN_PT; ++j) {
+    const int i = tid + 256 * j;
+    const int iy = i / IW, ix = i - iy * IW;
+    const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
+    const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    in_goff[j] = ok ? gy * a.w + gx : 0;
+    in_okmask |= ok ? (1u << j) : 0u;
+  }
+  const float* wslabs = a.wpacked + (long long)blockIdx.y * nchunks * SLAB;
+
+  float rin[CK][IN_PT];
+  unsigned have_mask = 0;    // bit c: channel c of the chunk in registers exists (ci < Cin)
+
+  // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves
+  auto dma_weights = [&](int chunk, int buf) {
+    const float* src = wslabs + (long long)chunk * SLAB;
+    float* dst = w_s + buf * SLAB;
+#pragma unroll
+    for (int p = 0; p < (SLAB / 256 + 3) / 4; ++p) {
+      const int piece = wave + 4 * p;
+      if (piece < SLAB / 256)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+            (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+    }
+  };
+
+  auto prefetch_input = [&](int c0) {
+    have_mask = 0;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const int ci = c0 + c;
+      const float* plane = a.src[0].ptr;   // any valid address; the value is dropped at commit
+      if (ci < a.cin) {
+        int cc = ci;
+        for (int s = 0; s < a.n_src; ++s) {
+          if (cc < a.src[s].channels) {
+            plane = a.src[s].ptr + (long long)n * a.src[s].batch_stride + (long long)cc * a.src[s].chan_stride;
+            have_mask |= 1u << c;
+            break;
+          }
+          cc -= a.src[s].channels;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < IN_PT; ++j) rin[c][j] = plane[in_goff[j]];
+    }
+  };
+
+  auto commit_input = [&](int buf) {
+    float* dst = in_s + buf * IN_BUF;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const bool have = (have_mask >> c) & 1u;
+#pragma unroll
+      for (int j = 0; j < IN_PT; ++j) {
+        float v = (have && ((in_okmask >> j) & 1u)) ? rin[c][j] : 0.f;
+        if (a.in_act) v = dvc::leaky(v, a.in_slope);
+        const int i = tid + 256 * j;
+        if (CHS % 256 == 0 || i < CHS) dst[c * CHS + i] = v;
+      }
+    }
+  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -78,125 +190,124 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* bbase = in_s + half * CHS + (wave * NT * SL) * IWP + l32 * SL;
-  const float* abase = w_s + (half * TAPS) * CBP + l32;
+  const int b_lane = half * CHS + (wave * NT * SL) * IW + l32 * SL;
+  const int a_lane = (half * TAPS) * CB + l32;
 
-  // top-left input coordinate of the staged tile
-  const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
-  const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
-  constexpr int GS = (KS == 1) ? S : 1;  // global step between staged pixels
+  // ---- prologue: chunk 0 into buffer 0
+  dma_weights(0, 0);
+  prefetch_input(0);
+  commit_input(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
-  for (int c0 = 0; c0 < a.cin; c0 += CK) {
+  for (int k = 0; k < nchunks; ++k) {
+    const int cur = k & 1;
+    if (k + 1 < nchunks) {   // chunk k+1 in flight during the MFMA phase
+      dma_weights(k + 1, cur ^ 1);
+      prefetch_input((k + 1) * CK);
+    }
+    const float* bbase = in_s + cur * IN_BUF + b_lane;
+    const float* abase = w_s + cur * SLAB + a_lane;
+    constexpr int T = (CK / 2) * TAPS;
+    float av[2][MT], bv[2][NT];
+    auto fetch = [&](int t, int slot) {
+      const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CB + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (k + 1 < nchunks) commit_input(cur ^ 1);   // buffer cur^1 was last read before the previous barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
     __syncthreads();
-    // ---- stage CK input channels (zero outside the image / past Cin)
-    for (int c = 0; c < CK; ++c) {
-      const int ci = c0 + c;
-      const float* plane = nullptr;
-      if (ci < a.cin) {
-        int cc = ci;
-        for (int s = 0; s < a.n_src; ++s) {
-          if (cc < a.src[s].channels) {
-            plane = a.src[s].ptr + (long long)n * a.src[s].batch_stride +
-                    (long long)cc * a.src[s].chan_stride;
-            break;
-          }
-          cc -= a.src[s].channels;
-        }
-      }
-      float* dst = in_s + c * CHS;
-      for (int i = tid; i < IH * IW; i += 256) {
-        const int iy = i / IW, ix = i - iy * IW;
-        const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
-        float v = 0.f;
-        if (plane != nullptr && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
-          v = plane[(long long)gy * a.w + gx];
-        if (a.in_act) v = dvc::leaky(v, a.in_slope);
-        dst[iy * IWP + ix] = v;
-      }
-    }
-    // ---- stage the weight slab [k][cout] for this chunk (OIHW -> transposed)
-    for (int i = tid; i < CB * KCH; i += 256) {
-      const int co = i / KCH, kk = i - co * KCH;
-      const int ci = c0 + kk / TAPS;
-      const int gco = cb0 + co;
-      float v = 0.f;
-      if (gco < a.cout && ci < a.cin)
-        v = a.weight[((long long)gco * a.cin + c0) * TAPS + kk];
-      w_s[kk * CBP + co] = v;
-    }
-    __syncthreads();
-    // ---- MFMA over the chunk
-#pragma unroll
-    for (int cp = 0; cp < CK / 2; ++cp) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          float av[MT], bv[NT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            av[mt] = abase[(2 * cp * TAPS + ky * KS + kx) * CBP + mt * 32];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            bv[nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IWP + kx];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-        }
-      }
-    }
   }
 
-  // ---- epilogue: bias, activation, residual, (pixel-shuffle) store
+  // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
+  // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
   const int ox = ox0 + l32;
   if (ox >= a.wo) return;
+  const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int oy = oy0 + wave * NT + nt;
       if (oy >= a.ho) continue;
+      float rv[16], rv2[16];
       if (!a.ps) {
+        const long long pix = (long long)oy * a.wo + ox;
+        if (has_res) {   // issue all residual loads of the tile before using any
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int cc = co < a.cout ? co : 0;
+            rv[r] = a.res[(long long)n * a.rbs + (long long)cc * a.rcs + pix];
+            if (has_scale) rv[r] *= a.res_scale[n * a.c_final + cc];
+            rv2[r] = has_res2 ? a.res2[(long long)n * a.r2bs + (long long)cc * a.r2cs + pix] : 0.f;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (co >= a.cout) continue;
-          float v = acc[mt][nt][r];
-          if (a.bias) v += a.bias[co];
+          float v = acc[mt][nt][r] + bias_r[r];
           if (a.out_act) v = dvc::leaky(v, a.out_slope);
-          const long long pix = (long long)oy * a.wo + ox;
-          if (a.res) {
-            float rv = a.res[(long long)n * a.rbs + (long long)co * a.rcs + pix];
-            if (a.res_scale) rv *= a.res_scale[n * a.c_final + co];
-            v += rv;
-            if (a.res2) v += a.res2[(long long)n * a.r2bs + (long long)co * a.r2cs + pix];
+          if (has_res) {
+            v += rv[r];
+            if (has_res2) v += rv2[r];
           }
           a.out[(long long)n * a.obs + (long long)co * a.ocs + pix] = v;
         }
       } else {
+        // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); registers
+        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.
+        if (has_res) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int cc = co < a.cout ? co : 0;
+            const int c2 = cc >> 2, dy = (cc >> 1) & 1;
+            const long long pix = (long long)(2 * oy + dy) * (2 * a.wo) + 2 * ox;
+            const float2 t = *reinterpret_cast<const float2*>(a.res + (long long)n * a.rbs + (long long)c2 * a.rcs + pix);
+            const float sc = has_scale ? a.res_scale[n * a.c_final + c2] : 1.f;
+            rv[r] = has_scale ? t.x * sc : t.x;
+            rv[r + 1] = has_scale ? t.y * sc : t.y;
+            if (has_res2) {
+              const float2 u = *reinterpret_cast<const float2*>(a.res2 + (long long)n * a.r2bs + (long long)c2 * a.r2cs + pix);
+              rv2[r] = u.x;
+              rv2[r + 1] = u.y;
+            }
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // even
           if (co >= a.cout) continue;
-          float v0 = acc[mt][nt][r], v1 = acc[mt][nt][r + 1];
-          if (a.bias) { v0 += a.bias[co]; v1 += a.bias[co + 1]; }
+          float v0 = acc[mt][nt][r] + bias_r[r], v1 = acc[mt][nt][r + 1] + bias_r[r + 1];
           if (a.out_act) { v0 = dvc::leaky(v0, a.out_slope); v1 = dvc::leaky(v1, a.out_slope); }
+          if (has_res) {
+            v0 += rv[r]; v1 += rv[r + 1];
+            if (has_res2) { v0 += rv2[r]; v1 += rv2[r + 1]; }
+          }
           const int c2 = co >> 2, dy = (co >> 1) & 1;
           const long long pix = (long long)(2 * oy + dy) * (2 * a.wo) + 2 * ox;
-          if (a.res) {
-            const float* rp = a.res + (long long)n * a.rbs + (long long)c2 * a.rcs + pix;
-            float r0 = rp[0], r1 = rp[1];
-            if (a.res_scale) { const float sc = a.res_scale[n * a.c_final + c2]; r0 *= sc; r1 *= sc; }
-            v0 += r0; v1 += r1;
-            if (a.res2) {
-              const float* qp = a.res2 + (long long)n * a.r2bs + (long long)c2 * a.r2cs + pix;
-              v0 += qp[0]; v1 += qp[1];
-            }
-          }
-          float2* op = reinterpret_cast<float2*>(a.out + (long long)n * a.obs + (long long)c2 * a.ocs + pix);
-          *op = make_float2(v0, v1);
+          *reinterpret_cast<float2*>(a.out + (long long)n * a.obs + (long long)c2 * a.ocs + pix) = make_float2(v0, v1);
         }
       }
     }
@@ -205,37 +316,90 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32_kernel(const ConvArgs a)
 
 template <int KS, int S, int MT, int NT>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
-  constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT;
+  using G = Geo<KS, S, MT, NT>;
+  static bool attr_set = false;   // LDS above the 64 KiB default needs the opt-in once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
+      return DVC_EHIP;
+    }
+    attr_set = true;
+  }
   ConvArgs b = a;
-  const int tiles_y = (a.ho + TH - 1) / TH;
-  b.tiles_x = (a.wo + TW - 1) / TW;
-  dim3 grid(b.tiles_x * tiles_y, (a.cout + CB - 1) / CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT>), grid, dim3(256), 0, st, b);
+  const int tiles_y = (a.ho + G::TH - 1) / G::TH;
+  b.tiles_x = (a.wo + G::TW - 1) / G::TW;
+  dim3 grid(b.tiles_x * tiles_y, (a.cout + G::CB - 1) / G::CB, batch);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT>), grid, dim3(256), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
+}
+
+// Rows of 32 pixels per wave: the largest of max_nt / ... / 1 that still yields >= 2 workgroups per CU.
+inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
+  const long long cblocks = (a.cout + 32 * mt - 1) / (32 * mt);
+  const long long tx = (a.wo + 31) / 32;
+  for (int nt = max_nt; nt > 1; nt >>= 1) {
+    const long long blocks = (long long)((a.ho + 4 * nt - 1) / (4 * nt)) * tx * cblocks * batch;
+    if (blocks >= 512) return nt;
+  }
+  return 1;
 }
 
 template <int KS, int S>
 int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   const int mt = a.cout > 32 ? 2 : 1;
-  // big tiles (16 x 32 pixels) only when they still give the 256 CUs several blocks each
-  const long long big_blocks = (long long)((a.ho + 15) / 16) * ((a.wo + 31) / 32) *
-                               ((a.cout + 32 * mt - 1) / (32 * mt)) * batch;
-  const int nt = big_blocks >= 1024 ? 4 : 1;
-  if (mt == 2) return nt == 4 ? launch<KS, S, 2, 4>(a, batch, st) : launch<KS, S, 2, 1>(a, batch, st);
-  return nt == 4 ? launch<KS, S, 1, 4>(a, batch, st) : launch<KS, S, 1, 1>(a, batch, st);
+  // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
+  // workgroups per CU, so those stop at 8 rows
+  const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : 4);
+  if (mt == 2) {
+    if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 2, 4>(a, batch, st); }
+    if (nt == 2) return launch<KS, S, 2, 2>(a, batch, st);
+    return launch<KS, S, 2, 1>(a, batch, st);
+  }
+  if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4>(a, batch, st); }
+  if (nt == 2) return launch<KS, S, 1, 2>(a, batch, st);
+  return launch<KS, S, 1, 1>(a, batch, st);
+}
+
+int check_geometry(int cout, int cin, int ks, int stride, const char* who) {
+  DVC_REQUIRE(ks == 1 || ks == 3 || ks == 7, "%s: ksize=%d unsupported", who, ks);
+  DVC_REQUIRE(stride == 1 || stride == 2, "%s: stride=%d unsupported", who, stride);
+  DVC_REQUIRE(!(ks == 7 && stride != 1), "%s: 7x7 stride 2 unsupported", who);
+  DVC_REQUIRE(cout >= 1 && cin >= 1, "%s: bad channel counts", who);
+  DVC_REQUIRE((long long)cout * cin * ks * ks < (1LL << 31), "%s: weight too large", who);
+  return DVC_OK;
 }
 
 }  // namespace
 
+extern "C" int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride) {
+  if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_packed_weight_floats")) return DVC_EINVAL;
+  const int cb = cout_block_of(cout), ck = chunk_of(ksize, stride);
+  return (int64_t)((cout + cb - 1) / cb) * ((cin + ck - 1) / ck) * slab_floats(ksize, stride, cb);
+}
+
+extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                      float* packed, void* stream) {
+  if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_pack_weight")) return rc;
+  DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_pack_weight: null pointer");
+  DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_pack_weight: packed buffer must be 16-byte aligned");
+  const int cb = cout_block_of(cout), ck = chunk_of(ksize, stride);
+  const int slab = slab_floats(ksize, stride, cb), nchunks = (cin + ck - 1) / ck;
+  const long long total = (long long)((cout + cb - 1) / cb) * nchunks * slab;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                     packed, cout, cin, ksize, ck, cb, slab, nchunks, total);
+  return dvc::check_launch("pack_weight_kernel");
+}
+
 extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(p != nullptr, "dvc_conv2d: null params");
   DVC_REQUIRE(p->n_src >= 1 && p->n_src <= DVC_MAX_SRC, "dvc_conv2d: n_src=%d not in 1..%d", p->n_src, DVC_MAX_SRC);
-  DVC_REQUIRE(p->ksize == 1 || p->ksize == 3 || p->ksize == 7, "dvc_conv2d: ksize=%d unsupported", p->ksize);
-  DVC_REQUIRE(p->stride == 1 || p->stride == 2, "dvc_conv2d: stride=%d unsupported", p->stride);
-  DVC_REQUIRE(!(p->ksize == 7 && p->stride != 1), "dvc_conv2d: 7x7 stride 2 unsupported");
-  DVC_REQUIRE(p->batch >= 1 && p->in_h >= 1 && p->in_w >= 1 && p->out_channels >= 1, "dvc_conv2d: bad dims");
+  DVC_REQUIRE(p->batch >= 1 && p->in_h >= 1 && p->in_w >= 1, "dvc_conv2d: bad dims");
   DVC_REQUIRE(p->batch <= 65535, "dvc_conv2d: batch too large");
-  DVC_REQUIRE(p->weight != nullptr && p->out.ptr != nullptr, "dvc_conv2d: null weight/out");
+  DVC_REQUIRE((long long)p->in_h * p->in_w < (1LL << 31), "dvc_conv2d: plane too large");
+  DVC_REQUIRE(p->weight_packed != nullptr && p->out.ptr != nullptr, "dvc_conv2d: null weight/out");
+  DVC_REQUIRE(reinterpret_cast<uintptr_t>(p->weight_packed) % 16 == 0, "dvc_conv2d: packed weight must be 16-byte aligned");
   DVC_REQUIRE(!p->pixel_shuffle || p->out_channels % 4 == 0, "dvc_conv2d: pixel_shuffle needs Cout %% 4 == 0");
   ConvArgs a{};
   int cin = 0;
@@ -245,6 +409,7 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
     a.src[s] = p->src[s];
     cin += p->src[s].channels;
   }
+  if (int rc = check_geometry(p->out_channels, cin, p->ksize, p->stride, "dvc_conv2d")) return rc;
   a.n_src = p->n_src;
   a.cin = cin;
   a.h = p->in_h;
@@ -253,7 +418,7 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   const int pad = p->ksize / 2;
   a.ho = (p->in_h + 2 * pad - p->ksize) / p->stride + 1;
   a.wo = (p->in_w + 2 * pad - p->ksize) / p->stride + 1;
-  a.weight = p->weight;
+  a.wpacked = p->weight_packed;
   a.bias = p->bias;
   a.out = p->out.ptr;
   a.obs = p->out.batch_stride;
@@ -271,8 +436,15 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(a.ocs >= plane, "dvc_conv2d: out channel stride %lld < plane %lld", a.ocs, plane);
   DVC_REQUIRE(!a.res || a.rcs >= plane, "dvc_conv2d: residual channel stride too small");
   DVC_REQUIRE(!a.res2 || (a.res && a.r2cs >= plane), "dvc_conv2d: residual2 needs residual and a full channel stride");
-  DVC_REQUIRE(!a.ps || (reinterpret_cast<uintptr_t>(a.out) % 8 == 0 && a.obs % 2 == 0 && a.ocs % 2 == 0),
-              "dvc_conv2d: pixel_shuffle output must be 8-byte aligned with even strides");
+  DVC_REQUIRE(!a.res_scale || a.res, "dvc_conv2d: res_scale needs residual");
+  if (a.ps) {
+    DVC_REQUIRE(reinterpret_cast<uintptr_t>(a.out) % 8 == 0 && a.obs % 2 == 0 && a.ocs % 2 == 0,
+                "dvc_conv2d: pixel_shuffle output must be 8-byte aligned with even strides");
+    DVC_REQUIRE(!a.res || (reinterpret_cast<uintptr_t>(a.res) % 8 == 0 && a.rbs % 2 == 0 && a.rcs % 2 == 0),
+                "dvc_conv2d: pixel_shuffle residual must be 8-byte aligned with even strides");
+    DVC_REQUIRE(!a.res2 || (reinterpret_cast<uintptr_t>(a.res2) % 8 == 0 && a.r2bs % 2 == 0 && a.r2cs % 2 == 0),
+                "dvc_conv2d: pixel_shuffle residual2 must be 8-byte aligned with even strides");
+  }
   DVC_REQUIRE((long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) < 2147483647LL, "dvc_conv2d: too many tiles");
   a.in_slope = p->in_slope;
   a.out_slope = p->out_slope;

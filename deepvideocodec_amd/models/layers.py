@@ -33,11 +33,24 @@ class Conv2d(nn.Module):
         nn.init.xavier_normal_(self.weight, math.sqrt(2))
         nn.init.constant_(self.bias, 0.01)
 
+        self._packed = None       # kernel-layout image of `weight`
+        self._packed_key = None   # (storage address, version counter) it was built from
+
+    def packed_weight(self) -> Tensor:
+        """The slab-layout copy of the weight the kernel reads, rebuilt when the parameter is
+        modified in place (optimizer step, load_state_dict) or moved (`.to(device)`)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed is None or self._packed_key != key:
+            self._packed = ops.pack_conv_weight(w.detach().contiguous(), self.stride)
+            self._packed_key = key
+        return self._packed
+
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
                 pixel_shuffle=False, out=None) -> Tensor:
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
-                          pixel_shuffle=pixel_shuffle, out=out)
+                          pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight())
 
 
 def conv1x1(in_ch, out_ch, stride=1):

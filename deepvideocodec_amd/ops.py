@@ -61,13 +61,30 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def pack_conv_weight(weight: Tensor, stride: int = 1) -> Tensor:
+    """OIHW weight -> the slab layout dvc_conv2d reads (re-pack whenever the weight changes)."""
+    if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32 and weight.dim() == 4):
+        raise ValueError("pack_conv_weight: weight must be a contiguous fp32 OIHW GPU tensor")
+    cout, cin, k, k2 = weight.shape
+    if k != k2:
+        raise ValueError("pack_conv_weight: square kernels only")
+    lib = _lib.load()
+    n = check(lib.dvc_conv2d_packed_weight_floats(cout, cin, k, stride), "dvc_conv2d_packed_weight_floats")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib.dvc_conv2d_pack_weight(weight.data_ptr(), cout, cin, k, stride, packed.data_ptr(), _stream()),
+          "dvc_conv2d_pack_weight")
+    return packed
+
+
 def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
            in_slope: Optional[float] = None, out_slope: Optional[float] = None,
            residual: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
            residual2: Optional[Tensor] = None, pixel_shuffle: bool = False,
-           out: Optional[Tensor] = None) -> Tensor:
+           out: Optional[Tensor] = None, packed: Optional[Tensor] = None) -> Tensor:
     """See DvcConv2d in include/dvc_hip.h. `srcs` are concatenated along C; slopes of
-    None mean "no activation", 0.0 means ReLU."""
+    None mean "no activation", 0.0 means ReLU.  `weight` is the OIHW tensor (its shape
+    describes the layer); `packed` its pack_conv_weight() image -- packed on the fly if
+    not given (callers that reuse a weight should cache it)."""
     if isinstance(srcs, torch.Tensor):
         srcs = (srcs,)
     if not 1 <= len(srcs) <= _lib.DVC_MAX_SRC:
@@ -95,7 +112,9 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
         raise ValueError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
     p.n_src = len(srcs)
     p.batch, p.in_h, p.in_w = n, h, w
-    p.weight = weight.data_ptr()
+    if packed is None:
+        packed = pack_conv_weight(weight, stride)
+    p.weight_packed = packed.data_ptr()
     p.bias = _ptr(bias)
     p.out_channels = cout
     p.ksize = k

@@ -71,7 +71,8 @@ typedef struct DvcConv2d {
   DvcSrc src[DVC_MAX_SRC];
   int32_t n_src;
   int32_t batch, in_h, in_w;       /* input spatial size (all sources) */
-  const float* weight;             /* [Cout][Cin][k][k], Cin = sum(src.channels) */
+  const float* weight_packed;      /* dvc_conv2d_pack_weight() image of the [Cout][Cin][k][k] weight,
+                                      Cin = sum(src.channels); 16-byte aligned */
   const float* bias;               /* [Cout] or NULL */
   int32_t out_channels;            /* Cout of the convolution (before shuffle) */
   int32_t ksize;                   /* 1, 3 or 7 */
@@ -88,6 +89,15 @@ typedef struct DvcConv2d {
 } DvcConv2d;
 
 int dvc_conv2d(const DvcConv2d* p, void* stream);
+
+/* Weight layout of the convolution kernel: per block of 64 (Cout > 32) or 32 output
+ * channels and per K-chunk of input channels, one contiguous zero-padded slab
+ * [(ci - c0) * k*k + tap][co - cb0], so a slab is fetched global -> LDS in 1 KiB pieces.
+ * Re-pack whenever the nn.Conv2d weight (OIHW) changes.  The packed size depends on
+ * (Cout, Cin, k, stride); dvc_conv2d_packed_weight_floats returns it (negative on error). */
+int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
+int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
+                           int32_t stride, float* packed, void* stream);
 
 /* Backward bilinear warp, border clamp, flow in pixels (ch0 = x, ch1 = y):
  * layers.py:175-198 (`torch_warp` = grid_sample(bilinear, border, align_corners=True)). */
