@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvc_hip.so")
+# DVC_HIP_LIB overrides the in-tree library (kernel experiments); there is still no fallback.
+LIB_PATH = os.environ.get("DVC_HIP_LIB") or os.path.join(_HERE, "lib", "libdvc_hip.so")
 
 DVC_MAX_SRC = 4
 EB_PARAMS_PER_CHANNEL = 58

@@ -22,11 +22,6 @@ constexpr int kBypassBits = 4;
 constexpr uint32_t kMaxBypass = (1u << kBypassBits) - 1;
 constexpr uint64_t kRansL = 1ull << 31;
 
-struct Rec {
-  uint16_t start;
-  uint16_t range;  // 0 encodes 65536? never: range <= 65535 because every symbol keeps freq >= 1 and there are >= 2
-  uint8_t bypass;
-};
 
 inline void put(uint64_t& x, uint32_t*& ptr, uint32_t start, uint32_t freq) {
   const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
@@ -94,59 +89,53 @@ extern "C" int64_t dvc_rans_encode(const int32_t* symbols, const int32_t* indexe
                                    const int32_t* offsets, uint8_t* out, int64_t out_capacity) {
   DVC_REQUIRE(n >= 0 && (n == 0 || (symbols && indexes)) && cdfs && cdf_sizes && offsets && out,
               "dvc_rans_encode: null pointer");
-  std::vector<Rec> recs;
-  recs.reserve((size_t)n + 16);
-  for (int64_t i = 0; i < n; ++i) {
+  // Validate the tables once (the per-symbol loop then trusts them).
+  for (int32_t c = 0; c < n_cdfs; ++c) {
+    const int32_t* cdf = cdfs + (int64_t)c * cdf_stride;
+    const int32_t size = cdf_sizes[c];
+    DVC_REQUIRE(size >= 2 && size <= cdf_stride, "dvc_rans_encode: bad cdf size %d for table %d", size, c);
+    for (int32_t s = 0; s + 1 < size; ++s)
+      DVC_REQUIRE(cdf[s + 1] > cdf[s] && cdf[s] >= 0 && cdf[s + 1] <= (1 << kPrecision),
+                  "dvc_rans_encode: table %d is not strictly increasing within [0, 2^16]", c);
+  }
+  DVC_REQUIRE(out_capacity >= 8 && reinterpret_cast<uintptr_t>(out) % 4 == 0,
+              "dvc_rans_encode: output buffer must be 4-byte aligned and hold >= 8 bytes");
+  // One backward pass, words written from the end of `out` towards its start.  A symbol's
+  // records go out in reverse of their decode order: raw nibbles (last first), the nibble
+  // count, then the table symbol itself.
+  uint32_t* const buf_begin = reinterpret_cast<uint32_t*>(out);
+  uint32_t* const buf_end = buf_begin + out_capacity / 4;
+  uint32_t* ptr = buf_end;
+  uint64_t x = kRansL;
+  for (int64_t i = n; i-- > 0;) {
+    if (ptr - buf_begin < 16) {   // worst case per symbol: 1 + 10 nibble records, each <= 1 word
+      dvc::set_error("dvc_rans_encode: output capacity %lld bytes exhausted", (long long)out_capacity);
+      return DVC_ENOSPC;
+    }
     const int32_t idx = indexes[i];
     DVC_REQUIRE(idx >= 0 && idx < n_cdfs, "dvc_rans_encode: index %d out of range at %lld", idx, (long long)i);
     const int32_t* cdf = cdfs + (int64_t)idx * cdf_stride;
     const int32_t max_value = cdf_sizes[idx] - 2;
-    DVC_REQUIRE(max_value >= 0 && max_value + 1 < cdf_stride, "dvc_rans_encode: bad cdf size for index %d", idx);
     int32_t value = symbols[i] - offsets[idx];
-    uint32_t raw = 0;
-    if (value < 0) {
-      raw = (uint32_t)(-2 * (int64_t)value - 1);
+    if (value < 0 || value >= max_value) {
+      uint32_t raw;
+      if (value < 0) raw = (uint32_t)(-2 * (int64_t)value - 1);
+      else raw = (uint32_t)(2 * ((int64_t)value - max_value));
       value = max_value;
-    } else if (value >= max_value) {
-      raw = (uint32_t)(2 * ((int64_t)value - max_value));
-      value = max_value;
-    }
-    recs.push_back(Rec{(uint16_t)cdf[value], (uint16_t)(cdf[value + 1] - cdf[value]), 0});
-    if (value == max_value) {
       int32_t n_bypass = 0;
       while (n_bypass < 8 && (raw >> (n_bypass * kBypassBits)) != 0) ++n_bypass;
-      int32_t val = n_bypass;
-      while (val >= (int32_t)kMaxBypass) {
-        recs.push_back(Rec{(uint16_t)kMaxBypass, 0, 1});
-        val -= kMaxBypass;
-      }
-      recs.push_back(Rec{(uint16_t)val, 0, 1});
-      for (int32_t j = 0; j < n_bypass; ++j)
-        recs.push_back(Rec{(uint16_t)((raw >> (j * kBypassBits)) & kMaxBypass), 0, 1});
+      for (int32_t j = n_bypass; j-- > 0;) put_bits(x, ptr, (raw >> (j * kBypassBits)) & kMaxBypass);
+      // the count is sent as (n_bypass / 15) nibbles of 15 followed by n_bypass % 15
+      put_bits(x, ptr, (uint32_t)n_bypass % kMaxBypass);
+      for (int32_t q = n_bypass / (int32_t)kMaxBypass; q-- > 0;) put_bits(x, ptr, kMaxBypass);
     }
-  }
-  std::vector<uint32_t> buf(recs.size() + 2);
-  uint32_t* const buf_end = buf.data() + buf.size();
-  uint32_t* ptr = buf_end;
-  uint64_t x = kRansL;
-  for (size_t k = recs.size(); k-- > 0;) {
-    const Rec& r = recs[k];
-    if (!r.bypass) {
-      DVC_REQUIRE(r.range != 0, "dvc_rans_encode: zero-frequency symbol (CDF not strictly increasing)");
-      put(x, ptr, r.start, r.range);
-    } else {
-      put_bits(x, ptr, r.start);
-    }
+    put(x, ptr, (uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]));
   }
   ptr -= 2;
   ptr[0] = (uint32_t)x;
   ptr[1] = (uint32_t)(x >> 32);
   const int64_t nbytes = (int64_t)(buf_end - ptr) * 4;
-  if (nbytes > out_capacity) {
-    dvc::set_error("dvc_rans_encode: need %lld bytes, capacity %lld", (long long)nbytes, (long long)out_capacity);
-    return DVC_ENOSPC;
-  }
-  memcpy(out, ptr, (size_t)nbytes);
+  memmove(out, ptr, (size_t)nbytes);
   return nbytes;
 }
 
@@ -163,16 +152,36 @@ extern "C" int dvc_rans_decode(const uint8_t* data, int64_t n_bytes, const int32
   memcpy(words.data(), data, (size_t)n_bytes);
   Reader rd{words.data() + 2, words.data() + words.size(), (uint64_t)words[0] | ((uint64_t)words[1] << 32)};
   const uint32_t mask = (1u << kPrecision) - 1;
+  // Validate the tables once, and build per table a 257-entry bucket index: first[b] = largest s
+  // with cdf[s] <= b * 256.  The symbol of a cumulative value cum then lies in
+  // [first[cum >> 8], first[(cum >> 8) + 1]], a range of one or two entries for peaked tables.
+  constexpr int kBuckets = 256;
+  std::vector<uint16_t> first((size_t)n_cdfs * (kBuckets + 1));
+  for (int32_t c = 0; c < n_cdfs; ++c) {
+    const int32_t* cdf = cdfs + (int64_t)c * cdf_stride;
+    const int32_t size = cdf_sizes[c];
+    DVC_REQUIRE(size >= 2 && size <= cdf_stride && size <= 65536, "dvc_rans_decode: bad cdf size %d for table %d", size, c);
+    DVC_REQUIRE(cdf[0] == 0 && cdf[size - 1] == (1 << kPrecision), "dvc_rans_decode: table %d does not span [0, 2^16]", c);
+    int32_t s = 0;
+    uint16_t* f = first.data() + (size_t)c * (kBuckets + 1);
+    for (int b = 0; b <= kBuckets; ++b) {
+      const int32_t v = b << 8;
+      while (s + 1 < size - 1 && cdf[s + 1] <= v) {
+        DVC_REQUIRE(cdf[s + 1] >= cdf[s], "dvc_rans_decode: table %d is not monotone", c);
+        ++s;
+      }
+      f[b] = (uint16_t)s;
+    }
+  }
   for (int64_t i = 0; i < n; ++i) {
     const int32_t idx = indexes[i];
     DVC_REQUIRE(idx >= 0 && idx < n_cdfs, "dvc_rans_decode: index %d out of range at %lld", idx, (long long)i);
     const int32_t* cdf = cdfs + (int64_t)idx * cdf_stride;
-    const int32_t size = cdf_sizes[idx];
-    const int32_t max_value = size - 2;
-    DVC_REQUIRE(max_value >= 0 && size <= cdf_stride, "dvc_rans_decode: bad cdf size for index %d", idx);
+    const int32_t max_value = cdf_sizes[idx] - 2;
     const uint32_t cum = (uint32_t)(rd.x & mask);
-    // largest s with cdf[s] <= cum (cdf[0] = 0, cdf[size-1] = 65536): binary search
-    int32_t lo = 0, hi = size - 1;
+    // largest s with cdf[s] <= cum: bucket bounds, then bisection inside the bucket
+    const uint16_t* f = first.data() + (size_t)idx * (kBuckets + 1) + (cum >> 8);
+    int32_t lo = f[0], hi = f[1] + 1;
     while (hi - lo > 1) {
       const int32_t mid = (lo + hi) >> 1;
       if ((uint32_t)cdf[mid] <= cum) lo = mid; else hi = mid;

@@ -344,8 +344,9 @@ def context_model_params(sd, key, y, y_ref, z_hat, context3=None):
     return fused.chunk(2, 1)
 
 
-def context_model_forward(sd, ent: EntropyState, key, y, y_ref, context3=None):
-    """video_model.py:218-233 / 390-406."""
+def context_model_forward(sd, ent: EntropyState, key, y, y_ref, context3=None, trace=None):
+    """video_model.py:218-233 / 390-406.  `trace` (a dict) receives the pre-rounding values
+    (z - median, y - mean) so a test can tell a genuine rounding tie from a wrong result."""
     eb, gc = ent.eb[key], ent.gc[key]
     z = hyper_encoder(sd, key + ".hyper_encoder", y)
     _, z_lik = eb(z)
@@ -354,6 +355,8 @@ def context_model_forward(sd, ent: EntropyState, key, y, y_ref, context3=None):
     means, scales = context_model_params(sd, key, y, y_ref, z_hat, context3)
     y_hat, means_hat, scales_hat = dual_prior(sd, key, y, means, scales)
     _, y_lik = gc(y, scales_hat, means_hat)
+    if trace is not None:
+        trace[key] = {"z_pre": z - med, "z_hat": z_hat, "y_pre": y - means_hat, "y_hat": y_hat}
     return y_hat, {"y": y_lik, "z": z_lik}
 
 
@@ -391,15 +394,16 @@ def context_model_decompress(sd, ent: EntropyState, key, strings, shape, y_ref, 
 
 
 # ------------------------------------------------------------------ DMC
-def forward_inter(sd, ent, x_cur, dpb):
+def forward_inter(sd, ent, x_cur, dpb, trace=None):
     """video_model.py:556-579 (eval path, no pretrain flags)."""
     mv = me_spynet(sd, x_cur, dpb["x_ref"])
     y_mv = motion_encoder(sd, mv)
-    y_mv_hat, mv_lik = context_model_forward(sd, ent, "motion_context_model", y_mv, dpb.get("y_mv_ref"))
+    y_mv_hat, mv_lik = context_model_forward(sd, ent, "motion_context_model", y_mv, dpb.get("y_mv_ref"),
+                                             trace=trace)
     mv_hat = motion_decoder(sd, y_mv_hat)
     c1, c2, c3, x_warp = motion_compensation(sd, mv_hat, dpb)
     y = contextual_encoder(sd, x_cur, c1, c2, c3)
-    y_hat, fr_lik = context_model_forward(sd, ent, "frame_context_model", y, dpb.get("y_ref"), c3)
+    y_hat, fr_lik = context_model_forward(sd, ent, "frame_context_model", y, dpb.get("y_ref"), c3, trace=trace)
     res = contextual_decoder(sd, y_hat, c2, c3)
     feature, x_rec = recon_generation(sd, res, c1)
     return (x_rec, {"motion": mv_lik, "frame": fr_lik},
