@@ -115,21 +115,22 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   // ---- per-thread staging descriptors (identical for every channel and chunk)
   const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
   const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
-  int in_goff[IN_PT];        // offset inside a channel plane, 0 when the element is padding
-  unsigned in_okmask = 0;    // bit j: element j is inside the image
+  // byte offset of each staged element inside its channel plane; padding elements get an offset
+  // past every plane, for which the buffer load returns 0 (hardware range check) -- zero padding
+  // and the ragged last channel chunk cost no select instructions.
+  unsigned in_boff[IN_PT];
 #pragma unroll
   for (int j = 0; j < IN_PT; ++j) {
     const int i = tid + 256 * j;
     const int iy = i / IW, ix = i - iy * IW;
     const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
     const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    in_goff[j] = ok ? gy * a.w + gx : 0;
-    in_okmask |= ok ? (1u << j) : 0u;
+    in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
   }
+  const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
   const float* wslabs = a.wpacked + (long long)blockIdx.y * nchunks * SLAB;
 
   float rin[CK][IN_PT];
-  unsigned have_mask = 0;    // bit c: channel c of the chunk in registers exists (ci < Cin)
 
   // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves
   auto dma_weights = [&](int chunk, int buf) {
@@ -145,40 +146,66 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     }
   };
 
+  // The (up to 4) concatenated sources, hoisted out of the kernel-argument segment once (plain
+  // scalars, not arrays: resolving a channel to its plane inside the K loop must cost neither
+  // dependent scalar loads nor scratch traffic).
+  // (unused sources have channels == 0 and a null pointer: they are never selected)
+  const float* const sp0 = a.src[0].ptr + (long long)n * a.src[0].batch_stride;
+  const float* const sp1 = a.src[1].ptr + (long long)n * a.src[1].batch_stride;
+  const float* const sp2 = a.src[2].ptr + (long long)n * a.src[2].batch_stride;
+  const float* const sp3 = a.src[3].ptr + (long long)n * a.src[3].batch_stride;
+  const long long cs0 = a.src[0].chan_stride, cs1 = a.src[1].chan_stride;
+  const long long cs2 = a.src[2].chan_stride, cs3 = a.src[3].chan_stride;
+  const int e0 = a.src[0].channels;   // first channel past source 0, 1, 2
+  const int e1 = e0 + a.src[1].channels;
+  const int e2 = e1 + a.src[2].channels;
+  const int cin = a.cin;
+  const bool in_act = a.in_act != 0;
+  const float in_slope = a.in_slope;
+
   auto prefetch_input = [&](int c0) {
-    have_mask = 0;
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const int ci = c0 + c;
-      const float* plane = a.src[0].ptr;   // any valid address; the value is dropped at commit
-      if (ci < a.cin) {
-        int cc = ci;
-        for (int s = 0; s < a.n_src; ++s) {
-          if (cc < a.src[s].channels) {
-            plane = a.src[s].ptr + (long long)n * a.src[s].batch_stride + (long long)cc * a.src[s].chan_stride;
-            have_mask |= 1u << c;
-            break;
-          }
-          cc -= a.src[s].channels;
-        }
-      }
+      // plane of channel ci over the concatenated sources, as mask arithmetic (select chains on
+      // these scalars get turned into a private-memory lookup table by the compiler); the
+      // telescoping sums work because g2 implies g1 implies g0
+      const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
+      const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
+      const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
+      const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0), b1 = reinterpret_cast<unsigned long long>(sp1);
+      const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
+      const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
+      const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
+      const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
+      const bool have = ci < cin;
+      const unsigned long long pl = have ? base + 4ull * (unsigned long long)((long long)(ci - first) * cs) : b0;
+      // wave-uniform buffer descriptor (made provably so for the compiler): base = plane,
+      // size = H*W*4 bytes, or 0 past the last channel so that every load returns 0
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pl);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(pl >> 32));
+      const unsigned nbytes = __builtin_amdgcn_readfirstlane(have ? plane_bytes : 0u);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < IN_PT; ++j) rin[c][j] = plane[in_goff[j]];
+      for (int j = 0; j < IN_PT; ++j)
+        rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], 0, 0));
     }
   };
 
   auto commit_input = [&](int buf) {
-    float* dst = in_s + buf * IN_BUF;
+    float* dst = in_s + buf * IN_BUF + tid;
+    if (in_act) {   // wave-uniform
+#pragma unroll
+      for (int c = 0; c < CK; ++c)
+#pragma unroll
+        for (int j = 0; j < IN_PT; ++j) rin[c][j] = dvc::leaky(rin[c][j], in_slope);
+    }
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
-      const bool have = (have_mask >> c) & 1u;
 #pragma unroll
-      for (int j = 0; j < IN_PT; ++j) {
-        float v = (have && ((in_okmask >> j) & 1u)) ? rin[c][j] : 0.f;
-        if (a.in_act) v = dvc::leaky(v, a.in_slope);
-        const int i = tid + 256 * j;
-        if (CHS % 256 == 0 || i < CHS) dst[c * CHS + i] = v;
-      }
+      for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
+        if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
     }
   };
 
@@ -221,11 +248,17 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
+#ifndef DVC_NO_SCHED_PIN
+      __builtin_amdgcn_sched_barrier(0);          // keep those LDS reads ahead of this tap's MFMAs
+#endif
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+#ifndef DVC_NO_SCHED_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (k + 1 < nchunks) commit_input(cur ^ 1);   // buffer cur^1 was last read before the previous barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
@@ -234,15 +267,21 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 
   // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
   // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
+  // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
+  // 128 stores of a lane cost no 64-bit vector address arithmetic.
   const int ox = ox0 + l32;
   if (ox >= a.wo) return;
   const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
+  float* const out_n = a.out + (long long)n * a.obs;
+  const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
+  const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    const int cu0 = cb0 + mt * 32;   // wave-uniform first channel of the tile
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
     }
 #pragma unroll
@@ -251,63 +290,61 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       if (oy >= a.ho) continue;
       float rv[16], rv2[16];
       if (!a.ps) {
-        const long long pix = (long long)oy * a.wo + ox;
+        const unsigned pix = (unsigned)(oy * a.wo + ox);
+        const unsigned o_lane = 4u * half * (unsigned)a.ocs + pix;
+        const unsigned r_lane = 4u * half * (unsigned)a.rcs + pix;
+        const unsigned r2_lane = 4u * half * (unsigned)a.r2cs + pix;
         if (has_res) {   // issue all residual loads of the tile before using any
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int cc = co < a.cout ? co : 0;
-            rv[r] = a.res[(long long)n * a.rbs + (long long)cc * a.rcs + pix];
-            if (has_scale) rv[r] *= a.res_scale[n * a.c_final + cc];
-            rv2[r] = has_res2 ? a.res2[(long long)n * a.r2bs + (long long)cc * a.r2cs + pix] : 0.f;
+            const int cu = cu0 + (r & 3) + 8 * (r >> 2);
+            const bool ok = cu + 4 * half < a.cout;
+            // channels past Cout do not exist in the residual: such registers read channel 0, offset 0
+            const int cu_ld = cu < a.cout ? cu : 0;   // wave-uniform
+            rv[r] = (res_n + (long long)cu_ld * a.rcs)[ok ? r_lane : 0u];
+            if (has_scale) rv[r] *= a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)];
+            rv2[r] = has_res2 ? (res2_n + (long long)cu_ld * a.r2cs)[ok ? r2_lane : 0u] : 0.f;
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co >= a.cout) continue;
+          const int cu = cu0 + (r & 3) + 8 * (r >> 2);
+          if (cu + 4 * half >= a.cout) continue;
           float v = acc[mt][nt][r] + bias_r[r];
-          if (a.out_act) v = dvc::leaky(v, a.out_slope);
+          v = dvc::leaky(v, a.out_slope);   // slope 1 when the layer has no output activation
           if (has_res) {
             v += rv[r];
             if (has_res2) v += rv2[r];
           }
-          a.out[(long long)n * a.obs + (long long)co * a.ocs + pix] = v;
+          (out_n + (long long)cu * a.ocs)[o_lane] = v;
         }
       } else {
         // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); registers
-        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.
-        if (has_res) {
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int cc = co < a.cout ? co : 0;
-            const int c2 = cc >> 2, dy = (cc >> 1) & 1;
-            const long long pix = (long long)(2 * oy + dy) * (2 * a.wo) + 2 * ox;
-            const float2 t = *reinterpret_cast<const float2*>(a.res + (long long)n * a.rbs + (long long)c2 * a.rcs + pix);
-            const float sc = has_scale ? a.res_scale[n * a.c_final + c2] : 1.f;
-            rv[r] = has_scale ? t.x * sc : t.x;
-            rv[r + 1] = has_scale ? t.y * sc : t.y;
-            if (has_res2) {
-              const float2 u = *reinterpret_cast<const float2*>(a.res2 + (long long)n * a.r2bs + (long long)c2 * a.r2cs + pix);
-              rv2[r] = u.x;
-              rv2[r + 1] = u.y;
-            }
-          }
-        }
+        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.  With
+        // co = cu + 4 half: shuffled channel (cu>>2) + half, row parity (cu>>1)&1.
+        const unsigned wo2 = 2u * (unsigned)a.wo;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const int co = cb0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // even
-          if (co >= a.cout) continue;
+          const int cu = cu0 + (r & 3) + 8 * (r >> 2);   // even
+          const bool ok = cu + 4 * half < a.cout;
+          const int c2u = cu >> 2, dy = (cu >> 1) & 1;
+          const unsigned pix = (unsigned)(2 * oy + dy) * wo2 + 2u * (unsigned)ox;
           float v0 = acc[mt][nt][r] + bias_r[r], v1 = acc[mt][nt][r + 1] + bias_r[r + 1];
-          if (a.out_act) { v0 = dvc::leaky(v0, a.out_slope); v1 = dvc::leaky(v1, a.out_slope); }
-          if (has_res) {
-            v0 += rv[r]; v1 += rv[r + 1];
-            if (has_res2) { v0 += rv2[r]; v1 += rv2[r + 1]; }
+          v0 = dvc::leaky(v0, a.out_slope);
+          v1 = dvc::leaky(v1, a.out_slope);
+          if (has_res && ok) {
+            const float2 t = *reinterpret_cast<const float2*>(res_n + (long long)c2u * a.rcs + (half * (unsigned)a.rcs + pix));
+            const float sc = has_scale ? a.res_scale[n * a.c_final + c2u + half] : 1.f;
+            v0 += has_scale ? t.x * sc : t.x;
+            v1 += has_scale ? t.y * sc : t.y;
+            if (has_res2) {
+              const float2 u = *reinterpret_cast<const float2*>(res2_n + (long long)c2u * a.r2cs + (half * (unsigned)a.r2cs + pix));
+              v0 += u.x;
+              v1 += u.y;
+            }
           }
-          const int c2 = co >> 2, dy = (co >> 1) & 1;
-          const long long pix = (long long)(2 * oy + dy) * (2 * a.wo) + 2 * ox;
-          *reinterpret_cast<float2*>(a.out + (long long)n * a.obs + (long long)c2 * a.ocs + pix) = make_float2(v0, v1);
+          if (ok)
+            *reinterpret_cast<float2*>(out_n + (long long)c2u * a.ocs + (half * (unsigned)a.ocs + pix)) = make_float2(v0, v1);
         }
       }
     }
@@ -397,7 +434,7 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(p->n_src >= 1 && p->n_src <= DVC_MAX_SRC, "dvc_conv2d: n_src=%d not in 1..%d", p->n_src, DVC_MAX_SRC);
   DVC_REQUIRE(p->batch >= 1 && p->in_h >= 1 && p->in_w >= 1, "dvc_conv2d: bad dims");
   DVC_REQUIRE(p->batch <= 65535, "dvc_conv2d: batch too large");
-  DVC_REQUIRE((long long)p->in_h * p->in_w < (1LL << 31), "dvc_conv2d: plane too large");
+  DVC_REQUIRE((long long)p->in_h * p->in_w < (1LL << 28), "dvc_conv2d: plane too large");
   DVC_REQUIRE(p->weight_packed != nullptr && p->out.ptr != nullptr, "dvc_conv2d: null weight/out");
   DVC_REQUIRE(reinterpret_cast<uintptr_t>(p->weight_packed) % 16 == 0, "dvc_conv2d: packed weight must be 16-byte aligned");
   DVC_REQUIRE(!p->pixel_shuffle || p->out_channels % 4 == 0, "dvc_conv2d: pixel_shuffle needs Cout %% 4 == 0");
@@ -437,6 +474,9 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(!a.res || a.rcs >= plane, "dvc_conv2d: residual channel stride too small");
   DVC_REQUIRE(!a.res2 || (a.res && a.r2cs >= plane), "dvc_conv2d: residual2 needs residual and a full channel stride");
   DVC_REQUIRE(!a.res_scale || a.res, "dvc_conv2d: res_scale needs residual");
+  // per-lane offsets inside a 4-channel group are 32-bit
+  DVC_REQUIRE(4 * a.ocs + plane < (1LL << 30) && 4 * a.rcs + plane < (1LL << 30) && 4 * a.r2cs + plane < (1LL << 30),
+              "dvc_conv2d: channel stride too large for 32-bit lane offsets");
   if (a.ps) {
     DVC_REQUIRE(reinterpret_cast<uintptr_t>(a.out) % 8 == 0 && a.obs % 2 == 0 && a.ocs % 2 == 0,
                 "dvc_conv2d: pixel_shuffle output must be 8-byte aligned with even strides");
@@ -446,8 +486,8 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
                 "dvc_conv2d: pixel_shuffle residual2 must be 8-byte aligned with even strides");
   }
   DVC_REQUIRE((long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) < 2147483647LL, "dvc_conv2d: too many tiles");
-  a.in_slope = p->in_slope;
-  a.out_slope = p->out_slope;
+  a.in_slope = p->in_act ? p->in_slope : 1.0f;    // leaky(v, 1) == v exactly
+  a.out_slope = p->out_act ? p->out_slope : 1.0f;
   a.in_act = p->in_act ? 1 : 0;
   a.out_act = p->out_act ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);

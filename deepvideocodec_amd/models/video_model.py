@@ -440,6 +440,16 @@ class DMC(nn.Module):
         return x_rec, {"x_ref": x_rec, "feature_ref": feature, "y_ref": y_hat, "y_mv_ref": y_mv_hat}
 
     # ---- housekeeping ---------------------------------------------------------------------------
+    def prepare(self):
+        """Build every kernel-side weight image now (they are otherwise built on first use) and wait
+        for them; call once before driving the model from several host threads / streams."""
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.packed_weight()
+        if next(self.parameters()).is_cuda:
+            torch.cuda.synchronize()
+        return self
+
     def aux_loss(self):
         """List with one auxiliary (quantile) loss per context model (reference: :616-624)."""
         return [m.aux_loss() for m in self.modules() if isinstance(m, CompressionModel)]
