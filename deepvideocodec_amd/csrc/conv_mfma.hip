@@ -105,7 +105,21 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const int tid = threadIdx.x;
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
+  // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
+  // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
+  // of them: the halo columns and rows shared by neighbouring tiles are then fetched into one L2
+  // once instead of into up to three.  (Any launch order gives correct results; this is locality.)
+  int tile;
+  {
+    const int nt = gridDim.x;
+    const int s = (int)((blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 7;   // XCD phase of this grid row
+    const int u = blockIdx.x + s, k = u & 7;
+    // launch slots of this row that land on XCDs < k: F(s + nt) - F(s), F(m) = (m / 8) k + min(m % 8, k)
+    const int m1 = s + nt;
+    const int before = (m1 >> 3) * k + min(m1 & 7, k) - min(s, k);
+    const int first_u = s + ((k - s) & 7);
+    tile = before + ((u - first_u) >> 3);
+  }
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int cb0 = blockIdx.y * CB;
