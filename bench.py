@@ -64,6 +64,31 @@ def codec_gop(net, frames, clamp):
     return nbytes, recs
 
 
+def conv_variant(n, cout, ho, wo, k, stride):
+    """(MT, NT) template arguments the library picks for a convolution (the tile is 4*NT x 32
+    pixels x 32*MT output channels; NT is the largest of 4/2/1 that still gives >= 512 workgroups,
+    3x3 stride-2 layers stop at 2) -- used only to attribute probe timings to kernel names."""
+    mt = 2 if cout > 32 else 1
+    nt = 2 if (stride == 2 and k != 1) else 4
+    cblocks, tx = (cout + 32 * mt - 1) // (32 * mt), (wo + 31) // 32
+    while nt > 1 and ((ho + 4 * nt - 1) // (4 * nt)) * tx * cblocks * n < 512:
+        nt //= 2
+    return mt, nt
+
+
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed counter summary
+    (profiles/r*_pmc_traffic.json, written by tools/pmc_summary.py from separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command); None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rec = json.load(f).get("kernels", {}).get(kernel)
+    return None if rec is None else rec["traffic_bytes_per_launch"]
+
+
 class ConvProbe:
     """Brackets every convolution launch with events on the launch stream and tallies the
     algorithmic FLOPs (2 * N * Cout * Ho * Wo * Cin * k * k) per kernel variant."""
@@ -81,13 +106,15 @@ class ConvProbe:
             cout, cin, k, _ = weight.shape
             ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
             flops = 2.0 * n * cout * ho * wo * cin * k * k
-            mt = 2 if cout > 32 else 1
-            big = ((ho + 15) // 16) * ((wo + 31) // 32) * ((cout + 32 * mt - 1) // (32 * mt)) * n >= 1024
+            # compulsory bytes: every input, residual and output element once, plus the weights
+            nres = sum(kw.get(r) is not None for r in ("residual", "residual2"))
+            nbytes = 4.0 * (n * cin * h * w + (1 + nres) * n * cout * ho * wo + cout * cin * k * k)
+            mt, nt = conv_variant(n, cout, ho, wo, k, stride)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = self.orig(srcs, weight, bias, stride=stride, **kw)
             e1.record()
-            self.records.append(((k, stride, mt, 4 if big else 1), flops, e0, e1))
+            self.records.append(((k, stride, mt, nt), flops, e0, e1, nbytes))
             return out
         self.ops.conv2d = probed
         return self
@@ -98,11 +125,12 @@ class ConvProbe:
     def summary(self):
         torch.cuda.synchronize()
         per = {}
-        for key, flops, e0, e1 in self.records:
-            d = per.setdefault(key, [0.0, 0.0, 0])
+        for key, flops, e0, e1, nbytes in self.records:
+            d = per.setdefault(key, [0.0, 0.0, 0, 0.0])
             d[0] += flops
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
+            d[3] += nbytes
         return per
 
 
@@ -262,11 +290,13 @@ def main():
         dom = max(per.items(), key=lambda kv: kv[1][1])
         all_flops = sum(v[0] for v in per.values())
         all_time = sum(v[1] for v in per.values())
-        (k, st, mt, nt), (fl, tm, cnt) = dom
-        roof = {"bound": "mfma", "kernel": f"conv_mfma_f32_kernel<{k},{st},{mt},{nt}>",
+        (k, st, mt, nt), (fl, tm, cnt, nb) = dom
+        kname = f"conv_mfma_f32_kernel<{k},{st},{mt},{nt}>"
+        roof = {"bound": "mfma", "kernel": kname,
                 "achieved": fl / tm / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / tm / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "frac": fl / tm / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(kname),
                 "launches": cnt, "avg_launch_ms": tm / cnt * 1e3, "gflop_per_launch": fl / cnt / 1e9,
+                "algorithmic_bytes_per_launch": nb / cnt,
                 "all_conv_variants": {"achieved": all_flops / all_time / 1e12,
                                       "frac": all_flops / all_time / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                       "conv_ms_per_frame": all_time / 2 * 1e3,
