@@ -46,6 +46,7 @@ struct ConvArgs {
   float in_slope, out_slope;
   int in_act, out_act, ps;
   int tiles_x;
+  int vec4;               // output / residual rows allow 16-byte accesses
 };
 
 // input channels staged per K-chunk (even)
@@ -283,12 +284,104 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
   // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
   // 128 stores of a lane cost no 64-bit vector address arithmetic.
-  const int ox = ox0 + l32;
-  if (ox >= a.wo) return;
   const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
   float* const out_n = a.out + (long long)n * a.obs;
   const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
   const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
+
+  if (a.vec4) {
+    // Fast path (everything 16-byte aligned).  Store instructions, not bytes, are what the epilogue
+    // pays for, so each 32 channel x 32 pixel accumulator tile is turned through a wave-private LDS
+    // tile ([channel][pixel], row stride RS) and leaves as 16-byte stores: 4 per lane instead of 16.
+    // All waves are past the K loop's last barrier, so the staging buffers are free; a wave's LDS
+    // instructions execute in order, so its reads see its own writes without a barrier.
+    constexpr int RS = 36;
+    static_assert(G::LDS_BYTES >= 4 * 32 * RS * 4, "epilogue tiles do not fit the staging buffers");
+    float* const tl = lds + wave * (32 * RS);
+    const int sub = lane >> 3, px4 = 4 * (lane & 7);       // plain: 8 lanes x 16 B per channel row
+    const int row = lane >> 4, px2 = 2 * (lane & 15);      // shuffle: 16 lanes x 16 B per output row
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int cu0 = cb0 + mt * 32;
+      float bias_r[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + wave * NT + nt;
+        if (oy >= a.ho) continue;   // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = dvc::leaky(acc[mt][nt][r] + bias_r[r], a.out_slope);
+        if (!a.ps) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ch = cu0 + 8 * q + sub;
+            float4 v = *reinterpret_cast<const float4*>(tl + (8 * q + sub) * RS + px4);
+            if (ch < a.cout && ox0 + px4 < a.wo) {
+              const long long pix = (long long)oy * a.wo + ox0 + px4;
+              if (has_res) {
+                const float4 t = *reinterpret_cast<const float4*>(res_n + ch * a.rcs + pix);
+                if (has_scale) {
+                  const float sc = a.res_scale[n * a.c_final + ch];
+                  // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
+                  v.x = __fadd_rn(v.x, __fmul_rn(t.x, sc)); v.y = __fadd_rn(v.y, __fmul_rn(t.y, sc));
+                  v.z = __fadd_rn(v.z, __fmul_rn(t.z, sc)); v.w = __fadd_rn(v.w, __fmul_rn(t.w, sc));
+                } else {
+                  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (has_res2) {
+                  const float4 u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix);
+                  v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+              }
+              *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix) = v;
+            }
+          }
+        } else {
+          // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)): an output
+          // row interleaves two adjacent conv channels; a lane takes 2 pixels of both = 4 outputs
+          const long long wo2 = 2LL * a.wo;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * q + row;                  // output row of the tile: (channel, dy)
+            const int c2l = rr >> 1, dy = rr & 1, chl = 4 * c2l + 2 * dy;
+            const int c2 = (cu0 >> 2) + c2l;
+            const float2 e = *reinterpret_cast<const float2*>(tl + chl * RS + px2);
+            const float2 o = *reinterpret_cast<const float2*>(tl + (chl + 1) * RS + px2);
+            float4 v = make_float4(e.x, o.x, e.y, o.y);
+            if (cu0 + chl < a.cout && ox0 + px2 < a.wo) {
+              const long long pix = (2LL * oy + dy) * wo2 + 2 * (ox0 + px2);
+              if (has_res) {
+                const float4 t = *reinterpret_cast<const float4*>(res_n + c2 * a.rcs + pix);
+                if (has_scale) {
+                  const float sc = a.res_scale[n * a.c_final + c2];
+                  // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
+                  v.x = __fadd_rn(v.x, __fmul_rn(t.x, sc)); v.y = __fadd_rn(v.y, __fmul_rn(t.y, sc));
+                  v.z = __fadd_rn(v.z, __fmul_rn(t.z, sc)); v.w = __fadd_rn(v.w, __fmul_rn(t.w, sc));
+                } else {
+                  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (has_res2) {
+                  const float4 u = *reinterpret_cast<const float4*>(res2_n + c2 * a.r2cs + pix);
+                  v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+              }
+              *reinterpret_cast<float4*>(out_n + c2 * a.ocs + pix) = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // General path: one 4-byte store per accumulator register.
+  const int ox = ox0 + l32;
+  if (ox >= a.wo) return;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int cu0 = cb0 + mt * 32;   // wave-uniform first channel of the tile
@@ -316,7 +409,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
             // channels past Cout do not exist in the residual: such registers read channel 0, offset 0
             const int cu_ld = cu < a.cout ? cu : 0;   // wave-uniform
             rv[r] = (res_n + (long long)cu_ld * a.rcs)[ok ? r_lane : 0u];
-            if (has_scale) rv[r] *= a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)];
+            if (has_scale) rv[r] = __fmul_rn(rv[r], a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)]);
             rv2[r] = has_res2 ? (res2_n + (long long)cu_ld * a.r2cs)[ok ? r2_lane : 0u] : 0.f;
           }
         }
@@ -327,8 +420,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           float v = acc[mt][nt][r] + bias_r[r];
           v = dvc::leaky(v, a.out_slope);   // slope 1 when the layer has no output activation
           if (has_res) {
-            v += rv[r];
-            if (has_res2) v += rv2[r];
+            v = __fadd_rn(v, rv[r]);
+            if (has_res2) v = __fadd_rn(v, rv2[r]);
           }
           (out_n + (long long)cu * a.ocs)[o_lane] = v;
         }
@@ -349,8 +442,8 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           if (has_res && ok) {
             const float2 t = *reinterpret_cast<const float2*>(res_n + (long long)c2u * a.rcs + (half * (unsigned)a.rcs + pix));
             const float sc = has_scale ? a.res_scale[n * a.c_final + c2u + half] : 1.f;
-            v0 += has_scale ? t.x * sc : t.x;
-            v1 += has_scale ? t.y * sc : t.y;
+            v0 = __fadd_rn(v0, has_scale ? __fmul_rn(t.x, sc) : t.x);
+            v1 = __fadd_rn(v1, has_scale ? __fmul_rn(t.y, sc) : t.y);
             if (has_res2) {
               const float2 u = *reinterpret_cast<const float2*>(res2_n + (long long)c2u * a.r2cs + (half * (unsigned)a.r2cs + pix));
               v0 += u.x;
@@ -500,6 +593,15 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
                 "dvc_conv2d: pixel_shuffle residual2 must be 8-byte aligned with even strides");
   }
   DVC_REQUIRE((long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) < 2147483647LL, "dvc_conv2d: too many tiles");
+  {
+    // 16-byte epilogue accesses: every row start and every 4-pixel (shuffle: 2-pixel) group aligned
+    auto al = [](const void* q, long long bs, long long cs) {
+      return reinterpret_cast<uintptr_t>(q) % 16 == 0 && bs % 4 == 0 && cs % 4 == 0;
+    };
+    // (a shuffled store covers conv pixels 2k, 2k+1; a plain one pixels 4k .. 4k+3)
+    a.vec4 = (a.ps ? a.wo % 2 == 0 : a.wo % 4 == 0) && al(a.out, a.obs, a.ocs) && (!a.res || al(a.res, a.rbs, a.rcs)) &&
+             (!a.res2 || al(a.res2, a.r2bs, a.r2cs));
+  }
   a.in_slope = p->in_act ? p->in_slope : 1.0f;    // leaky(v, 1) == v exactly
   a.out_slope = p->out_act ? p->out_slope : 1.0f;
   a.in_act = p->in_act ? 1 : 0;

@@ -109,6 +109,28 @@ def test_conv2d_epilogues():
     close(got, want)
 
 
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (6, 10), (7, 7), (8, 12), (17, 30), (5, 64)])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_conv2d_epilogue_paths_stay_inside_output(H, W, shuffle):
+    """Odd and even widths pick the 16-byte or the 4-byte store path; the destination is a slice
+    in the middle of a sentinel-filled buffer that must come back untouched around it."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(100 * H + W + int(shuffle))
+    cout = 8 if shuffle else 5
+    x = torch.randn(2, 16, H, W, generator=g)
+    w = torch.randn(cout, 16, 3, 3, generator=g) / 12
+    b = torch.randn(cout, generator=g)
+    cf, Ho, Wo = (cout // 4, 2 * H, 2 * W) if shuffle else (cout, H, W)
+    res = torch.randn(2, cf, Ho, Wo, generator=g)
+    want = F.conv2d(x, w, b, padding=1)
+    want = (F.pixel_shuffle(want, 2) if shuffle else want) + res
+    pad = 4   # channels of guard band either side of the slice (keeps it 16-byte aligned when H*W % 4 == 0)
+    buf = torch.full((2, cf + 2 * pad, Ho, Wo), 7.5, device="cuda:0")
+    got = ops.conv2d(dev(x), dev(w), dev(b), pixel_shuffle=shuffle, residual=dev(res), out=buf[:, pad:pad + cf])
+    close(got, want)
+    assert bool((buf[:, :pad] == 7.5).all()) and bool((buf[:, pad + cf:] == 7.5).all())
+
+
 def test_flow_warp_and_resampling_match_reference_fixture():
     from conftest import load_golden
     from deepvideocodec_amd import ops

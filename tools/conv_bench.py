@@ -47,8 +47,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
+    ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
     args = ap.parse_args()
     names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
+    if args.custom:
+        names = []
+        for spec in args.custom.split(";"):
+            v = tuple(int(t) for t in spec.split(","))
+            SHAPES["x" + "_".join(map(str, v))] = v
+            names.append("x" + "_".join(map(str, v)))
     torch.manual_seed(0)
     total_t = total_f = 0.0
     for name in names:
