@@ -80,6 +80,19 @@ SIGNATURES = {
     "dvc_bits_scratch_floats": (_i64, [_i32]),
     "dvc_likelihood_bits": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _P]),
     "dvc_sq_err_sum": (C.c_int, [_SRC, _SRC, _i32, _i32, _i32, _P, _P, _P]),
+    "dvc_conv2d_wgrad_scratch_floats": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "dvc_conv2d_wgrad": (C.c_int, [_SRC, _i32, _i32, _i32, _i32, _i32, _f32, _P, _i32, _i32, _i32, _P, _P, _P]),
+    "dvc_act_grad": (C.c_int, [_SRC, _SRC, _f32, _i32, _P, _i32, _i32, _i32, _i32, _P]),
+    "dvc_mul_act_grad": (C.c_int, [_SRC, _SRC, _f32, _DST, _i32, _i32, _i32, _P]),
+    "dvc_zero_upsample2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _i32, _i32, _P]),
+    "dvc_add_scaled": (C.c_int, [_SRC, _SRC, _P, _SRC, _DST, _i32, _i32, _i32, _P]),
+    "dvc_scale_planes": (C.c_int, [_SRC, _P, _DST, _i32, _i32, _i32, _P]),
+    "dvc_plane_dot_scratch_floats": (_i64, [_i32, _i32]),
+    "dvc_plane_dot": (C.c_int, [_SRC, _SRC, _i32, _i32, _i32, _i32, _P, _P, _P]),
+    "dvc_flow_warp_backward": (C.c_int, [_SRC, _SRC, _SRC, _DST, _DST, _i32, _i32, _i32, _P]),
+    "dvc_avg_pool2_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
+    "dvc_max_pool2_backward": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
+    "dvc_bilinear_up2_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
     "dvc_rans_encode": (_i64, [_P, _P, _i64, _P, _i32, _i32, _P, _P, _P, _i64]),
     "dvc_rans_decode": (C.c_int, [_P, _i64, _P, _i64, _P, _i32, _i32, _P, _P, _P]),
     "dvc_pmf_to_quantized_cdf": (C.c_int, [_P, _i32, _i32, _P]),

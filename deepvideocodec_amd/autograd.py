@@ -1,0 +1,175 @@
+"""torch.autograd bindings of the HIP kernels: every Function's forward and backward launch only
+entry points of libdvc_hip.so (through ops.py); torch supplies the tape, the memory and the
+accumulation of gradients that reach one tensor from several consumers.
+
+The reference gets these gradients from torch.autograd over ATen ops (loss.backward() at
+dmc/train.py:329-336); the functions here are the adjoints of the fused forward kernels, so a
+training step runs the same HIP forward as inference plus the kernels in csrc/backward.hip and
+csrc/conv_wgrad.hip.
+"""
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _rows_ok(t: Tensor) -> Tensor:
+    """Gradients arrive with arbitrary strides (expanded, transposed ...): make rows contiguous."""
+    if t.dim() == 4 and (t.size(3) == 1 or t.stride(3) == 1) and (t.size(2) == 1 or t.stride(2) == t.size(3)) \
+            and t.stride(1) >= t.size(2) * t.size(3) and (t.size(0) == 1 or t.stride(0) >= t.size(1) * t.stride(1)):
+        return t
+    return t.contiguous()
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act_out(conv(act_in(cat(srcs))) + bias), optionally PixelShuffle(2)-ed (nn.Conv2d +
+    LeakyReLU / ReLU / PixelShuffle / torch.cat of the reference graph)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, *srcs):
+        out = ops.conv2d(srcs, weight, bias, stride=stride, in_slope=in_slope, out_slope=out_slope,
+                         pixel_shuffle=pixel_shuffle, packed=packed)
+        ctx.cfg = (stride, in_slope, out_slope, pixel_shuffle, bias is not None)
+        ctx.save_for_backward(weight, out if out_slope is not None else None, *srcs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        stride, in_slope, out_slope, ps, has_bias = ctx.cfg
+        weight, out, *srcs = ctx.saved_tensors
+        cout, cin, k, _ = weight.shape
+        n, _, h, w = srcs[0].shape
+        pad = k // 2
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        g = _rows_ok(g)
+        if out_slope is None and not ps and g.is_contiguous():
+            g_pre = g
+        else:
+            g_pre = ops.act_grad(g, out, 1.0 if out_slope is None else out_slope, ps, (n, cout, ho, wo))
+        need = ctx.needs_input_grad
+        gw = ops.conv2d_wgrad(srcs, g_pre, weight.shape, stride, in_slope) if need[0] else None
+        gb = ops.plane_dot(g_pre, None, sum_batch=True) if (has_bias and need[1]) else None
+        gsrcs = [None] * len(srcs)
+        if any(need[7:]):
+            # data gradient = stride-1 convolution of (zero-upsampled) g_pre with the flipped,
+            # transposed kernel -- the same MFMA kernel as the forward pass
+            wt = weight.flip(2, 3).transpose(0, 1).contiguous()
+            gin = ops.zero_upsample2(g_pre, h, w) if stride == 2 else g_pre
+            gx = ops.conv2d(gin, wt, None, stride=1)
+            c0 = 0
+            for i, s in enumerate(srcs):
+                c1 = c0 + s.size(1)
+                if need[7 + i]:
+                    gs = gx[:, c0:c1]
+                    gsrcs[i] = ops.mul_act_grad(gs, s, in_slope) if in_slope is not None else gs
+                c0 = c1
+        return (gw, gb, None, None, None, None, None, *gsrcs)
+
+
+def conv2d(srcs, weight, bias, stride=1, in_slope=None, out_slope=None, residual=None, res_scale=None,
+           residual2=None, pixel_shuffle=False, packed=None):
+    """Differentiable ops.conv2d.  The residual adds are taken out of the convolution epilogue
+    (their adjoint needs the pre-residual activation) and run as add_scaled."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = (srcs,)
+    y = _Conv2d.apply(weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, *srcs)
+    if residual is not None:
+        y = add_scaled(y, residual, res_scale, residual2)
+    return y
+
+
+class _AddScaled(torch.autograd.Function):
+    """a + b * scale[n, c] (+ c2)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, c2):
+        ctx.save_for_backward(b if scale is not None else None, scale)
+        ctx.has_c2 = c2 is not None
+        return ops.add_scaled(a, b, scale, c2)
+
+    @staticmethod
+    def backward(ctx, g):
+        b, scale = ctx.saved_tensors
+        g = _rows_ok(g)
+        need = ctx.needs_input_grad
+        gb = gs = None
+        if scale is None:
+            gb = g if need[1] else None
+        else:
+            if need[1]:
+                gb = ops.scale_planes(g, scale)
+            if need[2]:
+                gs = ops.plane_dot(g, b).view_as(scale)
+        return (g if need[0] else None, gb, gs, g if (ctx.has_c2 and need[3]) else None)
+
+
+def add_scaled(a, b, scale=None, c2=None):
+    return _AddScaled.apply(a, b, scale, c2)
+
+
+class _FlowWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, flow):
+        ctx.save_for_backward(src, flow)
+        return ops.flow_warp(src, flow)
+
+    @staticmethod
+    def backward(ctx, g):
+        src, flow = ctx.saved_tensors
+        gs, gf = ops.flow_warp_backward(src, flow, _rows_ok(g), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gs, gf
+
+
+def flow_warp(src, flow):
+    return _FlowWarp.apply(src, flow)
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.cfg = (x.size(2), x.size(3), scale)
+        return ops.avg_pool2(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, scale = ctx.cfg
+        return ops.avg_pool2_backward(_rows_ok(g), h, w, scale), None
+
+
+def avg_pool2(x, scale=1.0):
+    return _AvgPool2.apply(x, scale)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.max_pool2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.max_pool2_backward(x, _rows_ok(g))
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _BilinearUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.cfg = (x.size(2), x.size(3), scale)
+        return ops.bilinear_up2(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, scale = ctx.cfg
+        return ops.bilinear_up2_backward(_rows_ok(g), h, w, scale), None
+
+
+def bilinear_up2(x, scale=1.0):
+    return _BilinearUp2.apply(x, scale)

@@ -1,0 +1,452 @@
+// Backward (gradient) kernels of the HBM-bound ops of the DMC path, plus the small helpers the
+// convolution gradients need around the MFMA kernels: activation-derivative masks,
+// PixelShuffle un-shuffle, zero-insertion upsampling for stride-2 data gradients, per-plane dot
+// products (bias / gate gradients), and the warp / pooling / bilinear adjoints.
+// Same conventions as the forward kernels: one lane per pixel, consecutive lanes = consecutive x.
+#include "dvc_common.h"
+
+namespace {
+
+using dvc::stream_grid;
+
+struct Src { const float* p; long long bs, cs; int c; };
+struct Dst { float* p; long long bs, cs; };
+
+inline Src mk(const DvcSrc* s) { return Src{s->ptr, s->batch_stride, s->chan_stride, s->channels}; }
+inline Dst mk(const DvcDst* d) { return Dst{d->ptr, d->batch_stride, d->chan_stride}; }
+
+int check_plane(const DvcSrc* s, long long plane, const char* who) {
+  DVC_REQUIRE(s != nullptr && s->ptr != nullptr && s->channels >= 1, "%s: null/empty source", who);
+  DVC_REQUIRE(s->chan_stride >= plane, "%s: channel stride < H*W", who);
+  return DVC_OK;
+}
+#define CHECK_SRC(s, plane, who) do { int rc_ = check_plane((s), (plane), (who)); if (rc_) return rc_; } while (0)
+#define CHECK_DST(d, plane, who) \
+  DVC_REQUIRE((d) != nullptr && (d)->ptr != nullptr && (d)->chan_stride >= (int64_t)(plane), "%s: bad destination", who)
+
+#define FOREACH(total_expr)                                                             \
+  const long long total_ = (total_expr);                                                \
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_; i += (long long)gridDim.x * 256)
+
+// ------------------------------------------------------------------ conv helpers
+// Gradient w.r.t. the conv output before activation, in conv layout (N, C, ho, wo):
+//   gpre = g * act'(t),  act'(t) = t > 0 ? 1 : slope   (t = stored activation output),
+// g and t given in the stored layout, i.e. PixelShuffle(2)-ed when `ps`.
+__global__ __launch_bounds__(256) void act_grad_kernel(Src g, Src t, int has_t, float slope, int ps, float* out,
+                                                       int batch, int c, int ho, int wo) {
+  FOREACH((long long)batch * c * ho * wo) {
+    const int ox = (int)(i % wo);
+    long long q = i / wo;
+    const int oy = (int)(q % ho); q /= ho;
+    const int co = (int)(q % c), n = (int)(q / c);
+    long long off_g, off_t;
+    if (ps) {
+      const long long pix = (long long)(2 * oy + ((co >> 1) & 1)) * (2 * wo) + 2 * ox + (co & 1);
+      off_g = n * g.bs + (co >> 2) * g.cs + pix;
+      off_t = n * t.bs + (co >> 2) * t.cs + pix;
+    } else {
+      const long long pix = (long long)oy * wo + ox;
+      off_g = n * g.bs + co * g.cs + pix;
+      off_t = n * t.bs + co * t.cs + pix;
+    }
+    float v = g.p[off_g];
+    if (has_t) v = t.p[off_t] > 0.f ? v : v * slope;
+    out[i] = v;
+  }
+}
+
+// out = g * (x > 0 ? 1 : slope): the input-activation derivative applied to a data gradient
+__global__ __launch_bounds__(256) void mul_act_grad_kernel(Src g, Src x, Dst out, float slope, int batch, int h, int w) {
+  const long long hw = (long long)h * w;
+  FOREACH((long long)batch * g.c * hw) {
+    const long long pix = i % hw;
+    const long long q = i / hw;
+    const int c = (int)(q % g.c), n = (int)(q / g.c);
+    const float gv = g.p[n * g.bs + c * g.cs + pix];
+    out.p[n * out.bs + c * out.cs + pix] = x.p[n * x.bs + c * x.cs + pix] > 0.f ? gv : gv * slope;
+  }
+}
+
+// dst (H x W) = src (h x w) placed on the even sites, zeros elsewhere
+__global__ __launch_bounds__(256) void zero_upsample2_kernel(Src src, Dst out, int batch, int h, int w, int H, int W) {
+  FOREACH((long long)batch * src.c * H * W) {
+    const int x = (int)(i % W);
+    long long q = i / W;
+    const int y = (int)(q % H); q /= H;
+    const int c = (int)(q % src.c), n = (int)(q / src.c);
+    float v = 0.f;
+    if (!(x & 1) && !(y & 1) && (y >> 1) < h && (x >> 1) < w)
+      v = src.p[n * src.bs + c * src.cs + (long long)(y >> 1) * w + (x >> 1)];
+    out.p[n * out.bs + c * out.cs + (long long)y * W + x] = v;
+  }
+}
+
+// out = a + b * scale[n, c] (+ c2): the un-fused form of the conv epilogue's residual adds
+__global__ __launch_bounds__(256) void add_scaled_kernel(Src a, Src b, const float* scale, Src c2, int has_c2, Dst out,
+                                                         int batch, int h, int w) {
+  const long long hw = (long long)h * w;
+  FOREACH((long long)batch * a.c * hw) {
+    const long long pix = i % hw;
+    const long long q = i / hw;
+    const int c = (int)(q % a.c), n = (int)(q / a.c);
+    float bv = b.p[n * b.bs + c * b.cs + pix];
+    if (scale != nullptr) bv = __fmul_rn(bv, scale[(long long)n * a.c + c]);
+    float v = __fadd_rn(a.p[n * a.bs + c * a.cs + pix], bv);
+    if (has_c2) v = __fadd_rn(v, c2.p[n * c2.bs + c * c2.cs + pix]);
+    out.p[n * out.bs + c * out.cs + pix] = v;
+  }
+}
+
+// out = x * scale[n, c]
+__global__ __launch_bounds__(256) void scale_planes_kernel(Src x, const float* scale, Dst out, int batch, int h, int w) {
+  const long long hw = (long long)h * w;
+  FOREACH((long long)batch * x.c * hw) {
+    const long long pix = i % hw;
+    const long long q = i / hw;
+    const int c = (int)(q % x.c), n = (int)(q / x.c);
+    out.p[n * out.bs + c * out.cs + pix] = x.p[n * x.bs + c * x.cs + pix] * scale[(long long)n * x.c + c];
+  }
+}
+
+// ------------------------------------------------------------------ plane dot products
+constexpr int SLICES = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* lds4) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void plane_dot_partial_kernel(Src a, Src b, int has_b, long long hw, float* partial) {
+  __shared__ float red[4];
+  const int slice = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const long long per = (hw + SLICES - 1) / SLICES;
+  const long long s0 = slice * per, s1 = s0 + per < hw ? s0 + per : hw;
+  const float* pa = a.p + n * a.bs + c * a.cs;
+  const float* pb = has_b ? b.p + n * b.bs + c * b.cs : nullptr;
+  float s = 0.f;
+  if (has_b) for (long long i = s0 + threadIdx.x; i < s1; i += 256) s += pa[i] * pb[i];
+  else for (long long i = s0 + threadIdx.x; i < s1; i += 256) s += pa[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[((long long)n * a.c + c) * SLICES + slice] = s;
+}
+
+// out[n*C + c] (sum_batch = 0) or out[c] = sum over n (sum_batch = 1), fixed order
+__global__ __launch_bounds__(256) void plane_dot_final_kernel(const float* partial, int batch, int channels,
+                                                              int sum_batch, float* out) {
+  const int total = sum_batch ? channels : batch * channels;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    float s = 0.f;
+    if (sum_batch) {
+      for (int n = 0; n < batch; ++n) {
+        const float* pp = partial + ((long long)n * channels + i) * SLICES;
+        float sn = 0.f;
+        for (int k = 0; k < SLICES; ++k) sn += pp[k];
+        s += sn;
+      }
+    } else {
+      const float* pp = partial + (long long)i * SLICES;
+      for (int k = 0; k < SLICES; ++k) s += pp[k];
+    }
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------ warp adjoint
+__device__ __forceinline__ float linspace_pm1(int idx, int steps) {
+  const float step = 2.0f / (float)(steps - 1);
+  const int halfway = steps / 2;
+  return idx < halfway ? -1.0f + step * (float)idx : 1.0f - step * (float)(steps - idx - 1);
+}
+
+// Adjoint of the backward warp (same coordinate arithmetic as the forward kernel).  gsrc must be
+// zeroed by the caller; it is accumulated with float atomics (several output pixels may sample
+// the same source pixel).  gflow follows grid_sample's rule: no gradient through a coordinate
+// that was clipped to the border (position <= 0 or >= size - 1).
+__global__ __launch_bounds__(256) void flow_warp_backward_kernel(Src src, Src flow, Src gout, Dst gsrc, int want_gsrc,
+                                                                 Dst gflow, int want_gflow, int batch, int h, int w) {
+  const long long hw = (long long)h * w;
+  FOREACH(hw * batch) {
+    const int n = (int)(i / hw);
+    const int pix = (int)(i - n * hw);
+    const int y = pix / w, x = pix - y * w;
+    const float* fp = flow.p + n * flow.bs + pix;
+    const float u = fp[0], v = fp[flow.cs];
+    const float sx = (float)((w - 1.0) / 2.0), sy = (float)((h - 1.0) / 2.0);
+    float gx = linspace_pm1(x, w) + u / sx;
+    float gy = linspace_pm1(y, h) + v / sy;
+    if (w == 1) gx = -1.0f + u / sx;
+    if (h == 1) gy = -1.0f + v / sy;
+    float fx = (gx + 1.0f) * sx, fy = (gy + 1.0f) * sy;
+    const float mx = (fx <= 0.f || fx >= (float)(w - 1)) ? 0.f : 1.f;
+    const float my = (fy <= 0.f || fy >= (float)(h - 1)) ? 0.f : 1.f;
+    fx = fminf((float)(w - 1), fmaxf(fx, 0.0f));
+    fy = fminf((float)(h - 1), fmaxf(fy, 0.0f));
+    const float xw = floorf(fx), yn = floorf(fy);
+    const float we = fx - xw, ee = 1.0f - we, ns = fy - yn, ss = 1.0f - ns;
+    const int ix = (int)xw, iy = (int)yn;
+    const bool in_e = ix + 1 < w, in_s = iy + 1 < h;
+    const int o_nw = iy * w + ix, o_ne = o_nw + 1, o_sw = o_nw + w, o_se = o_nw + w + 1;
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < gout.c; ++c) {
+      const float g = gout.p[n * gout.bs + c * gout.cs + pix];
+      if (want_gsrc) {
+        float* gs = gsrc.p + n * gsrc.bs + c * gsrc.cs;
+        atomicAdd(gs + o_nw, g * (ss * ee));
+        if (in_e) atomicAdd(gs + o_ne, g * (ss * we));
+        if (in_s) atomicAdd(gs + o_sw, g * (ns * ee));
+        if (in_e && in_s) atomicAdd(gs + o_se, g * (ns * we));
+      }
+      if (want_gflow) {
+        const float* sp = src.p + n * src.bs + c * src.cs;
+        const float nw = sp[o_nw];
+        const float ne = in_e ? sp[o_ne] : 0.f;
+        const float sw = in_s ? sp[o_sw] : 0.f;
+        const float se = (in_e && in_s) ? sp[o_se] : 0.f;
+        gix += g * ((ne - nw) * ss + (se - sw) * ns);
+        giy += g * ((sw - nw) * ee + (se - ne) * we);
+      }
+    }
+    if (want_gflow) {
+      float* gf = gflow.p + n * gflow.bs + pix;
+      gf[0] = (gix * sx * mx) / sx;
+      gf[gflow.cs] = (giy * sy * my) / sy;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pooling / bilinear adjoints
+__global__ __launch_bounds__(256) void avg_pool2_backward_kernel(Src g, Dst out, int batch, int h, int w, float scale) {
+  const int ho = h / 2, wo = w / 2;
+  FOREACH((long long)batch * g.c * h * w) {
+    const int x = (int)(i % w);
+    long long q = i / w;
+    const int y = (int)(q % h); q /= h;
+    const int c = (int)(q % g.c), n = (int)(q / g.c);
+    float v = 0.f;
+    if ((y >> 1) < ho && (x >> 1) < wo) v = 0.25f * scale * g.p[n * g.bs + c * g.cs + (long long)(y >> 1) * wo + (x >> 1)];
+    out.p[n * out.bs + c * out.cs + (long long)y * w + x] = v;
+  }
+}
+
+// gradient goes to the first maximum in scan order (0,0), (0,1), (1,0), (1,1)
+__global__ __launch_bounds__(256) void max_pool2_backward_kernel(Src xin, Src g, Dst out, int batch, int h, int w) {
+  const int ho = h / 2, wo = w / 2;
+  FOREACH((long long)batch * g.c * h * w) {
+    const int x = (int)(i % w);
+    long long q = i / w;
+    const int y = (int)(q % h); q /= h;
+    const int c = (int)(q % g.c), n = (int)(q / g.c);
+    float v = 0.f;
+    const int oy = y >> 1, ox = x >> 1;
+    if (oy < ho && ox < wo) {
+      const float* p = xin.p + n * xin.bs + c * xin.cs + (long long)(2 * oy) * w + 2 * ox;
+      int best = 0;
+      float bv = p[0];
+      if (p[1] > bv) { bv = p[1]; best = 1; }
+      if (p[w] > bv) { bv = p[w]; best = 2; }
+      if (p[w + 1] > bv) { bv = p[w + 1]; best = 3; }
+      if (best == ((y & 1) << 1 | (x & 1))) v = g.p[n * g.bs + c * g.cs + (long long)oy * wo + ox];
+    }
+    out.p[n * out.bs + c * out.cs + (long long)y * w + x] = v;
+  }
+}
+
+__device__ __forceinline__ void up2_coord(int o, int in, int& i0, int& i1, float& l0, float& l1) {
+  float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+// weight with which output coordinate o of the x2 upsampling reads input coordinate i
+__device__ __forceinline__ float up2_weight(int o, int i, int in) {
+  int i0, i1; float l0, l1;
+  up2_coord(o, in, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// gather form of the adjoint: input pixel (y, x) is read by output rows 2y-1 .. 2y+2 (cols likewise)
+__global__ __launch_bounds__(256) void bilinear_up2_backward_kernel(Src g, Dst out, int batch, int h, int w, float scale) {
+  const int ho = 2 * h, wo = 2 * w;
+  FOREACH((long long)batch * g.c * h * w) {
+    const int x = (int)(i % w);
+    long long q = i / w;
+    const int y = (int)(q % h); q /= h;
+    const int c = (int)(q % g.c), n = (int)(q / g.c);
+    const float* gp = g.p + n * g.bs + c * g.cs;
+    float s = 0.f;
+    for (int oy = 2 * y - 1; oy <= 2 * y + 2; ++oy) {
+      if (oy < 0 || oy >= ho) continue;
+      const float wy = up2_weight(oy, y, h);
+      if (wy == 0.f) continue;
+      float r = 0.f;
+      for (int ox = 2 * x - 1; ox <= 2 * x + 2; ++ox) {
+        if (ox < 0 || ox >= wo) continue;
+        r += up2_weight(ox, x, w) * gp[(long long)oy * wo + ox];
+      }
+      s += wy * r;
+    }
+    out.p[n * out.bs + c * out.cs + (long long)y * w + x] = s * scale;
+  }
+}
+
+}  // namespace
+
+#define LAUNCH_1D(kernel, total, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(stream_grid((total), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+extern "C" int dvc_act_grad(const DvcSrc* grad, const DvcSrc* act_out, float slope, int32_t pixel_shuffle,
+                            float* grad_pre, int32_t batch, int32_t channels, int32_t ho, int32_t wo, void* stream) {
+  DVC_REQUIRE(batch >= 1 && channels >= 1 && ho >= 1 && wo >= 1 && grad_pre != nullptr, "dvc_act_grad: bad arguments");
+  DVC_REQUIRE(!pixel_shuffle || channels % 4 == 0, "dvc_act_grad: pixel_shuffle needs C %% 4 == 0");
+  const long long plane = (long long)ho * wo * (pixel_shuffle ? 4 : 1);
+  const int stored_c = pixel_shuffle ? channels / 4 : channels;
+  CHECK_SRC(grad, plane, "dvc_act_grad(grad)");
+  DVC_REQUIRE(grad->channels == stored_c, "dvc_act_grad: grad has %d channels, expected %d", grad->channels, stored_c);
+  if (act_out != nullptr) {
+    CHECK_SRC(act_out, plane, "dvc_act_grad(act_out)");
+    DVC_REQUIRE(act_out->channels == stored_c, "dvc_act_grad: act_out channel mismatch");
+  }
+  const long long total = (long long)batch * channels * ho * wo;
+  LAUNCH_1D(act_grad_kernel, total, stream, mk(grad), act_out ? mk(act_out) : Src{nullptr, 0, 0, 0}, act_out ? 1 : 0,
+            slope, pixel_shuffle ? 1 : 0, grad_pre, batch, channels, ho, wo);
+  return dvc::check_launch("act_grad_kernel");
+}
+
+extern "C" int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcDst* out, int32_t batch,
+                                int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_mul_act_grad: bad dims");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(grad, plane, "dvc_mul_act_grad(grad)");
+  CHECK_SRC(x, plane, "dvc_mul_act_grad(x)");
+  DVC_REQUIRE(x->channels == grad->channels, "dvc_mul_act_grad: channel mismatch");
+  CHECK_DST(out, plane, "dvc_mul_act_grad");
+  LAUNCH_1D(mul_act_grad_kernel, (long long)batch * grad->channels * plane, stream, mk(grad), mk(x), mk(out), slope,
+            batch, h, w);
+  return dvc::check_launch("mul_act_grad_kernel");
+}
+
+extern "C" int dvc_zero_upsample2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                                  int32_t out_h, int32_t out_w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && out_h >= 2 * h - 1 && out_w >= 2 * w - 1, "dvc_zero_upsample2: bad dims");
+  CHECK_SRC(src, (long long)h * w, "dvc_zero_upsample2");
+  CHECK_DST(out, (long long)out_h * out_w, "dvc_zero_upsample2");
+  LAUNCH_1D(zero_upsample2_kernel, (long long)batch * src->channels * out_h * out_w, stream, mk(src), mk(out), batch,
+            h, w, out_h, out_w);
+  return dvc::check_launch("zero_upsample2_kernel");
+}
+
+extern "C" int dvc_add_scaled(const DvcSrc* a, const DvcSrc* b, const float* scale, const DvcSrc* c, const DvcDst* out,
+                              int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_add_scaled: bad dims");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(a, plane, "dvc_add_scaled(a)");
+  CHECK_SRC(b, plane, "dvc_add_scaled(b)");
+  DVC_REQUIRE(b->channels == a->channels, "dvc_add_scaled: channel mismatch");
+  if (c != nullptr) {
+    CHECK_SRC(c, plane, "dvc_add_scaled(c)");
+    DVC_REQUIRE(c->channels == a->channels, "dvc_add_scaled: channel mismatch");
+  }
+  CHECK_DST(out, plane, "dvc_add_scaled");
+  LAUNCH_1D(add_scaled_kernel, (long long)batch * a->channels * plane, stream, mk(a), mk(b), scale,
+            c ? mk(c) : Src{nullptr, 0, 0, 0}, c ? 1 : 0, mk(out), batch, h, w);
+  return dvc::check_launch("add_scaled_kernel");
+}
+
+extern "C" int dvc_scale_planes(const DvcSrc* x, const float* scale, const DvcDst* out, int32_t batch, int32_t h,
+                                int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && scale != nullptr, "dvc_scale_planes: bad arguments");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(x, plane, "dvc_scale_planes");
+  CHECK_DST(out, plane, "dvc_scale_planes");
+  LAUNCH_1D(scale_planes_kernel, (long long)batch * x->channels * plane, stream, mk(x), scale, mk(out), batch, h, w);
+  return dvc::check_launch("scale_planes_kernel");
+}
+
+extern "C" int64_t dvc_plane_dot_scratch_floats(int32_t batch, int32_t channels) {
+  return (int64_t)batch * channels * SLICES;
+}
+
+extern "C" int dvc_plane_dot(const DvcSrc* a, const DvcSrc* b, int32_t batch, int32_t h, int32_t w, int32_t sum_batch,
+                             float* scratch, float* out, void* stream) {
+  DVC_REQUIRE(batch >= 1 && batch <= 65535 && h >= 1 && w >= 1 && scratch && out, "dvc_plane_dot: bad arguments");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(a, plane, "dvc_plane_dot(a)");
+  DVC_REQUIRE(a->channels <= 65535, "dvc_plane_dot: too many channels");
+  if (b != nullptr) {
+    CHECK_SRC(b, plane, "dvc_plane_dot(b)");
+    DVC_REQUIRE(b->channels == a->channels, "dvc_plane_dot: channel mismatch");
+  }
+  hipLaunchKernelGGL(plane_dot_partial_kernel, dim3(SLICES, a->channels, batch), dim3(256), 0, (hipStream_t)stream,
+                     mk(a), b ? mk(b) : Src{nullptr, 0, 0, 0}, b ? 1 : 0, plane, scratch);
+  int rc = dvc::check_launch("plane_dot_partial_kernel");
+  if (rc) return rc;
+  const int total = sum_batch ? a->channels : batch * a->channels;
+  LAUNCH_1D(plane_dot_final_kernel, total, stream, (const float*)scratch, batch, a->channels, sum_batch ? 1 : 0, out);
+  return dvc::check_launch("plane_dot_final_kernel");
+}
+
+extern "C" int dvc_flow_warp_backward(const DvcSrc* src, const DvcSrc* flow, const DvcSrc* grad_out,
+                                      const DvcDst* grad_src, const DvcDst* grad_flow, int32_t batch, int32_t h,
+                                      int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_flow_warp_backward: bad dims");
+  const long long plane = (long long)h * w;
+  DVC_REQUIRE(plane < (1LL << 30), "dvc_flow_warp_backward: plane too large");
+  CHECK_SRC(src, plane, "dvc_flow_warp_backward(src)");
+  CHECK_SRC(flow, plane, "dvc_flow_warp_backward(flow)");
+  CHECK_SRC(grad_out, plane, "dvc_flow_warp_backward(grad_out)");
+  DVC_REQUIRE(flow->channels == 2 && grad_out->channels == src->channels, "dvc_flow_warp_backward: channel mismatch");
+  const bool ws = grad_src != nullptr && grad_src->ptr != nullptr, wf = grad_flow != nullptr && grad_flow->ptr != nullptr;
+  DVC_REQUIRE(ws || wf, "dvc_flow_warp_backward: nothing to compute");
+  if (ws) CHECK_DST(grad_src, plane, "dvc_flow_warp_backward(grad_src)");
+  if (wf) CHECK_DST(grad_flow, plane, "dvc_flow_warp_backward(grad_flow)");
+  LAUNCH_1D(flow_warp_backward_kernel, (long long)batch * plane, stream, mk(src), mk(flow), mk(grad_out),
+            ws ? mk(grad_src) : Dst{nullptr, 0, 0}, ws ? 1 : 0, wf ? mk(grad_flow) : Dst{nullptr, 0, 0}, wf ? 1 : 0, batch,
+            h, w);
+  return dvc::check_launch("flow_warp_backward_kernel");
+}
+
+extern "C" int dvc_avg_pool2_backward(const DvcSrc* grad_out, const DvcDst* grad_in, int32_t batch, int32_t h, int32_t w,
+                                      float scale, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 2 && w >= 2, "dvc_avg_pool2_backward: bad dims");
+  CHECK_SRC(grad_out, (long long)(h / 2) * (w / 2), "dvc_avg_pool2_backward");
+  CHECK_DST(grad_in, (long long)h * w, "dvc_avg_pool2_backward");
+  LAUNCH_1D(avg_pool2_backward_kernel, (long long)batch * grad_out->channels * h * w, stream, mk(grad_out), mk(grad_in),
+            batch, h, w, scale);
+  return dvc::check_launch("avg_pool2_backward_kernel");
+}
+
+extern "C" int dvc_max_pool2_backward(const DvcSrc* x, const DvcSrc* grad_out, const DvcDst* grad_in, int32_t batch,
+                                      int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 2 && w >= 2, "dvc_max_pool2_backward: bad dims");
+  CHECK_SRC(x, (long long)h * w, "dvc_max_pool2_backward(x)");
+  CHECK_SRC(grad_out, (long long)(h / 2) * (w / 2), "dvc_max_pool2_backward(grad_out)");
+  DVC_REQUIRE(x->channels == grad_out->channels, "dvc_max_pool2_backward: channel mismatch");
+  CHECK_DST(grad_in, (long long)h * w, "dvc_max_pool2_backward");
+  LAUNCH_1D(max_pool2_backward_kernel, (long long)batch * x->channels * h * w, stream, mk(x), mk(grad_out),
+            mk(grad_in), batch, h, w);
+  return dvc::check_launch("max_pool2_backward_kernel");
+}
+
+extern "C" int dvc_bilinear_up2_backward(const DvcSrc* grad_out, const DvcDst* grad_in, int32_t batch, int32_t h,
+                                         int32_t w, float scale, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_bilinear_up2_backward: bad dims");
+  CHECK_SRC(grad_out, (long long)4 * h * w, "dvc_bilinear_up2_backward");
+  CHECK_DST(grad_in, (long long)h * w, "dvc_bilinear_up2_backward");
+  LAUNCH_1D(bilinear_up2_backward_kernel, (long long)batch * grad_out->channels * h * w, stream, mk(grad_out),
+            mk(grad_in), batch, h, w, scale);
+  return dvc::check_launch("bilinear_up2_backward_kernel");
+}

@@ -321,3 +321,117 @@ def sq_err_sum(a: Tensor, b: Tensor) -> Tensor:
     check(lib.dvc_sq_err_sum(C.byref(_src(a)), C.byref(_src(b)), n, h, w, partial.data_ptr(), sse.data_ptr(),
                              _stream()), "dvc_sq_err_sum")
     return sse
+
+
+# ------------------------------------------------------------------------------------ gradients
+def conv2d_wgrad(srcs: Srcs, grad_pre: Tensor, wshape, stride: int = 1, in_slope: Optional[float] = None) -> Tensor:
+    """Weight gradient (OIHW) of conv2d; grad_pre = contiguous (N, Cout, ho, wo) gradient before the
+    output activation (see act_grad)."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = (srcs,)
+    cout, cin, k, _ = wshape
+    n, _, h, w = srcs[0].shape
+    if not grad_pre.is_contiguous() or grad_pre.dtype != torch.float32 or grad_pre.size(1) != cout:
+        raise ValueError("conv2d_wgrad: grad_pre must be a contiguous fp32 (N, Cout, ho, wo) tensor")
+    arr = (DvcSrc * len(srcs))(*[_src(s, f"wgrad src[{i}]") for i, s in enumerate(srcs)])
+    if sum(s.size(1) for s in srcs) != cin:
+        raise ValueError("conv2d_wgrad: sources do not add up to the weight's input channels")
+    lib = _lib.load()
+    nfl = check(lib.dvc_conv2d_wgrad_scratch_floats(cout, cin, k, stride, n, h, w), "dvc_conv2d_wgrad_scratch_floats")
+    scratch = torch.empty(nfl, dtype=torch.float32, device=grad_pre.device)
+    gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=grad_pre.device)
+    check(lib.dvc_conv2d_wgrad(arr, len(srcs), n, h, w, 0 if in_slope is None else 1,
+                               1.0 if in_slope is None else float(in_slope), grad_pre.data_ptr(), cout, k, stride,
+                               scratch.data_ptr(), gw.data_ptr(), _stream()), "dvc_conv2d_wgrad")
+    return gw
+
+
+def act_grad(grad: Tensor, act_out: Optional[Tensor], slope: float, pixel_shuffle: bool, conv_shape) -> Tensor:
+    n, c, ho, wo = conv_shape
+    out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=grad.device)
+    ao = C.byref(_src(act_out, "act_out")) if act_out is not None else None
+    check(_lib.load().dvc_act_grad(C.byref(_src(grad, "grad")), ao, float(slope), 1 if pixel_shuffle else 0,
+                                   out.data_ptr(), n, c, ho, wo, _stream()), "dvc_act_grad")
+    return out
+
+
+def mul_act_grad(grad: Tensor, x: Tensor, slope: float, out: Optional[Tensor] = None) -> Tensor:
+    n, c, h, w = grad.shape
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=grad.device)
+    check(_lib.load().dvc_mul_act_grad(C.byref(_src(grad, "grad")), C.byref(_src(x, "x")), float(slope),
+                                       C.byref(_dst(out)), n, h, w, _stream()), "dvc_mul_act_grad")
+    return out
+
+
+def zero_upsample2(x: Tensor, out_h: int, out_w: int) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, out_h, out_w), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_zero_upsample2(C.byref(_src(x)), C.byref(_dst(out)), n, h, w, out_h, out_w, _stream()),
+          "dvc_zero_upsample2")
+    return out
+
+
+def add_scaled(a: Tensor, b: Tensor, scale: Optional[Tensor] = None, c: Optional[Tensor] = None) -> Tensor:
+    """a + b * scale[n*C + ch] (+ c)."""
+    n, ch, h, w = a.shape
+    out = torch.empty((n, ch, h, w), dtype=torch.float32, device=a.device)
+    cc = C.byref(_src(c, "c")) if c is not None else None
+    check(_lib.load().dvc_add_scaled(C.byref(_src(a, "a")), C.byref(_src(b, "b")), _ptr(scale), cc, C.byref(_dst(out)),
+                                     n, h, w, _stream()), "dvc_add_scaled")
+    return out
+
+
+def scale_planes(x: Tensor, scale: Tensor) -> Tensor:
+    n, ch, h, w = x.shape
+    out = torch.empty((n, ch, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_scale_planes(C.byref(_src(x)), scale.data_ptr(), C.byref(_dst(out)), n, h, w, _stream()),
+          "dvc_scale_planes")
+    return out
+
+
+def plane_dot(a: Tensor, b: Optional[Tensor] = None, sum_batch: bool = False) -> Tensor:
+    """(N*C,) plane sums of a*b (or of a); (C,) summed over the batch too when sum_batch."""
+    n, ch, h, w = a.shape
+    lib = _lib.load()
+    scratch = torch.empty(lib.dvc_plane_dot_scratch_floats(n, ch), dtype=torch.float32, device=a.device)
+    out = torch.empty(ch if sum_batch else n * ch, dtype=torch.float32, device=a.device)
+    bb = C.byref(_src(b, "b")) if b is not None else None
+    check(lib.dvc_plane_dot(C.byref(_src(a, "a")), bb, n, h, w, 1 if sum_batch else 0, scratch.data_ptr(),
+                            out.data_ptr(), _stream()), "dvc_plane_dot")
+    return out
+
+
+def flow_warp_backward(src: Tensor, flow: Tensor, grad_out: Tensor, want_src=True, want_flow=True):
+    n, ch, h, w = src.shape
+    gs = torch.zeros((n, ch, h, w), dtype=torch.float32, device=src.device) if want_src else None
+    gf = torch.empty((n, 2, h, w), dtype=torch.float32, device=src.device) if want_flow else None
+    check(_lib.load().dvc_flow_warp_backward(
+        C.byref(_src(src, "src")), C.byref(_src(flow, "flow")), C.byref(_src(grad_out, "grad_out")),
+        C.byref(_dst(gs)) if gs is not None else None, C.byref(_dst(gf)) if gf is not None else None,
+        n, h, w, _stream()), "dvc_flow_warp_backward")
+    return gs, gf
+
+
+def avg_pool2_backward(grad_out: Tensor, h: int, w: int, scale: float = 1.0) -> Tensor:
+    n, ch = grad_out.shape[:2]
+    out = torch.empty((n, ch, h, w), dtype=torch.float32, device=grad_out.device)
+    check(_lib.load().dvc_avg_pool2_backward(C.byref(_src(grad_out)), C.byref(_dst(out)), n, h, w, float(scale),
+                                             _stream()), "dvc_avg_pool2_backward")
+    return out
+
+
+def max_pool2_backward(x: Tensor, grad_out: Tensor) -> Tensor:
+    n, ch, h, w = x.shape
+    out = torch.empty((n, ch, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().dvc_max_pool2_backward(C.byref(_src(x, "x")), C.byref(_src(grad_out, "grad_out")),
+                                             C.byref(_dst(out)), n, h, w, _stream()), "dvc_max_pool2_backward")
+    return out
+
+
+def bilinear_up2_backward(grad_out: Tensor, h: int, w: int, scale: float = 1.0) -> Tensor:
+    n, ch = grad_out.shape[:2]
+    out = torch.empty((n, ch, h, w), dtype=torch.float32, device=grad_out.device)
+    check(_lib.load().dvc_bilinear_up2_backward(C.byref(_src(grad_out)), C.byref(_dst(out)), n, h, w, float(scale),
+                                                _stream()), "dvc_bilinear_up2_backward")
+    return out

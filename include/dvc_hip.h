@@ -208,6 +208,61 @@ int dvc_sq_err_sum(const DvcSrc* a, const DvcSrc* b, int32_t batch, int32_t h, i
                    float* partial, float* sse, void* stream);
 
 /*
+ * ---- Gradients (training path).  The reference gets all of these from torch.autograd
+ * (loss.backward() at dmc/train.py:329-336); each entry point is the adjoint of one forward
+ * entry point above and cites the forward op's reference lines.
+ */
+
+/*
+ * Weight gradient of dvc_conv2d (nn.Conv2d backward w.r.t. weight):
+ *   gW[co][ci][ky][kx] = sum_{n,oy,ox} grad_out[n][co][oy][ox] * act_in(cat(srcs))[n][ci][oy*s+ky-p][ox*s+kx-p]
+ * grad_out is the gradient before the output activation, contiguous (N, Cout, ho, wo) -- see
+ * dvc_act_grad.  scratch needs dvc_conv2d_wgrad_scratch_floats() floats; grad_weight is OIHW.
+ * Deterministic (fixed summation order).
+ */
+int64_t dvc_conv2d_wgrad_scratch_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                        int32_t batch, int32_t in_h, int32_t in_w);
+int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch, int32_t in_h, int32_t in_w,
+                     int32_t in_act, float in_slope, const float* grad_out, int32_t out_channels,
+                     int32_t ksize, int32_t stride, float* scratch, float* grad_weight, void* stream);
+/* grad_pre (contiguous N, C, ho, wo) = grad * act'(act_out), act'(t) = t > 0 ? 1 : slope, with
+ * grad / act_out in the stored layout (PixelShuffle(2)-ed when pixel_shuffle); act_out NULL = no
+ * activation (pure un-shuffle / compaction).  LeakyReLU / ReLU / PixelShuffle backward. */
+int dvc_act_grad(const DvcSrc* grad, const DvcSrc* act_out, float slope, int32_t pixel_shuffle,
+                 float* grad_pre, int32_t batch, int32_t channels, int32_t ho, int32_t wo, void* stream);
+/* out = grad * (x > 0 ? 1 : slope): derivative of the fused input activation. */
+int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcDst* out,
+                     int32_t batch, int32_t h, int32_t w, void* stream);
+/* out (out_h x out_w) = src (h x w) on the even sites, zero elsewhere: turns the data gradient
+ * of a stride-2 convolution into a stride-1 convolution with the flipped kernel. */
+int dvc_zero_upsample2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,
+                       int32_t out_h, int32_t out_w, void* stream);
+/* out = a + b * scale[n*C + c] (+ c): un-fused residual / squeeze-excite adds (layers.py:72-81,
+ * 280, 297); scale and c may be NULL.  dvc_scale_planes: out = x * scale[n*C + c]. */
+int dvc_add_scaled(const DvcSrc* a, const DvcSrc* b, const float* scale, const DvcSrc* c,
+                   const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream);
+int dvc_scale_planes(const DvcSrc* x, const float* scale, const DvcDst* out, int32_t batch,
+                     int32_t h, int32_t w, void* stream);
+/* out[n*C + c] = sum_hw a*b (b NULL: sum_hw a); sum_batch != 0: out[c] = sum over n as well
+ * (bias gradient).  Two-stage, fixed order.  scratch: dvc_plane_dot_scratch_floats() floats. */
+int64_t dvc_plane_dot_scratch_floats(int32_t batch, int32_t channels);
+int dvc_plane_dot(const DvcSrc* a, const DvcSrc* b, int32_t batch, int32_t h, int32_t w,
+                  int32_t sum_batch, float* scratch, float* out, void* stream);
+/* Adjoint of dvc_flow_warp (layers.py:175-198): grad_src (pre-zeroed by the caller, accumulated
+ * with float atomics) and / or grad_flow; either destination may be NULL. */
+int dvc_flow_warp_backward(const DvcSrc* src, const DvcSrc* flow, const DvcSrc* grad_out,
+                           const DvcDst* grad_src, const DvcDst* grad_flow, int32_t batch,
+                           int32_t h, int32_t w, void* stream);
+/* Adjoints of dvc_avg_pool2 / dvc_max_pool2 / dvc_bilinear_up2; h, w are the INPUT dims of the
+ * forward op (so grad_in is h x w). */
+int dvc_avg_pool2_backward(const DvcSrc* grad_out, const DvcDst* grad_in, int32_t batch, int32_t h,
+                           int32_t w, float scale, void* stream);
+int dvc_max_pool2_backward(const DvcSrc* x, const DvcSrc* grad_out, const DvcDst* grad_in,
+                           int32_t batch, int32_t h, int32_t w, void* stream);
+int dvc_bilinear_up2_backward(const DvcSrc* grad_out, const DvcDst* grad_in, int32_t batch,
+                              int32_t h, int32_t w, float scale, void* stream);
+
+/*
  * Host range coder (no GPU involved): restates compressai.ans
  * RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as used at
  * video_model.py:238-239,250-251,257,273,283.  64-bit-state rANS, 32-bit words,
