@@ -93,6 +93,11 @@ SIGNATURES = {
     "dvc_avg_pool2_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
     "dvc_max_pool2_backward": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_bilinear_up2_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
+    "dvc_eb_backward_scratch_floats": (_i64, [_i32]),
+    "dvc_eb_backward": (C.c_int, [_SRC, _P, _SRC, _DST, _P, _P, _i32, _i32, _i32, _P]),
+    "dvc_dual_prior_pass1_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),
+    "dvc_dual_prior_pass2_backward": (C.c_int, [_SRC, _SRC, _SRC, _SRC, _P, _SRC, _SRC, _DST, _DST, _DST, _DST,
+                                                _i32, _i32, _i32, _P]),
     "dvc_rans_encode": (_i64, [_P, _P, _i64, _P, _i32, _i32, _P, _P, _P, _i64]),
     "dvc_rans_decode": (C.c_int, [_P, _i64, _P, _i64, _P, _i32, _i32, _P, _P, _P]),
     "dvc_pmf_to_quantized_cdf": (C.c_int, [_P, _i32, _i32, _P]),

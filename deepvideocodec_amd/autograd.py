@@ -173,3 +173,107 @@ class _BilinearUp2(torch.autograd.Function):
 
 def bilinear_up2(x, scale=1.0):
     return _BilinearUp2.apply(x, scale)
+
+
+class _SEGate(torch.autograd.Function):
+    """gate[n, c] = sigmoid(fc2 relu(fc1 mean_hw(x)))  (reference layers.py:267-280).  The plane
+    means run on the HIP reduction kernels; the adjoint of the two tiny FC layers (C x C/16
+    matrices on an (N, C) vector) is evaluated with torch on those few numbers."""
+
+    @staticmethod
+    def forward(ctx, x, fc1, fc2):
+        ctx.save_for_backward(x, fc1, fc2)
+        return ops.se_gate(x, fc1, fc2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, fc1, fc2 = ctx.saved_tensors
+        n, c, h, w = x.shape
+        mean = (ops.plane_dot(x) / float(h * w)).view(n, c)
+        with torch.enable_grad():
+            m = mean.detach().requires_grad_()
+            a, b = fc1.detach().requires_grad_(), fc2.detach().requires_grad_()
+            gate = torch.sigmoid(torch.relu(m @ a.t()) @ b.t())
+            gm, ga, gb = torch.autograd.grad(gate, (m, a, b), g.reshape(n, c))
+        gx = (gm / float(h * w)).view(n, c, 1, 1).expand(n, c, h, w) if ctx.needs_input_grad[0] else None
+        return gx, ga, gb
+
+
+def se_gate(x, fc1, fc2):
+    return _SEGate.apply(x, fc1, fc2)
+
+
+class _RoundSTE(torch.autograd.Function):
+    """round(z - median) + median with the identity as gradient (reference utils.py:149-152 used at
+    video_model.py:222-224)."""
+
+    @staticmethod
+    def forward(ctx, z, packed, medians):
+        return ops.eb_forward(z, packed, medians, want_likelihood=False)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def round_ste(z, packed, medians):
+    return _RoundSTE.apply(z, packed, medians)
+
+
+class _EBLikelihood(torch.autograd.Function):
+    """Factorized-prior likelihood of z + noise (compressai EntropyBottleneck.forward, training):
+    returns (z + noise, likelihood); differentiable w.r.t. z and the packed (C, 58) parameters."""
+
+    @staticmethod
+    def forward(ctx, z, packed, medians, noise):
+        out, lik, _ = ops.eb_forward(z, packed, medians, noise=noise)
+        ctx.save_for_backward(out, packed)
+        return out, lik
+
+    @staticmethod
+    def backward(ctx, g_out, g_lik):
+        out, packed = ctx.saved_tensors
+        gx, gp = ops.eb_backward(out, packed, _rows_ok(g_lik), want_gx=ctx.needs_input_grad[0])
+        if gx is not None and g_out is not None:
+            gx = gx + g_out
+        return gx, gp, None, None
+
+
+def eb_likelihood(z, packed, medians, noise):
+    return _EBLikelihood.apply(z, packed, medians, noise)
+
+
+class _DualPriorPass1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, means, scales):
+        return ops.dual_prior_pass1(y, means, scales)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dual_prior_pass1_backward(_rows_ok(g)), None, None
+
+
+def dual_prior_pass1(y, means, scales):
+    return _DualPriorPass1.apply(y, means, scales)
+
+
+class _DualPriorPass2(torch.autograd.Function):
+    """-> (y_hat, likelihood) of the second checkerboard pass (video_model.py:192-232)."""
+
+    @staticmethod
+    def forward(ctx, y, means, scales, spatial, noise):
+        r = ops.dual_prior_pass2(y, means, scales, spatial, noise=noise, want=("y_hat", "likelihood"))
+        ctx.save_for_backward(y, means, scales, spatial, noise)
+        return r["y_hat"], r["likelihood"]
+
+    @staticmethod
+    def backward(ctx, g_yhat, g_lik):
+        y, means, scales, spatial, noise = ctx.saved_tensors
+        gy, gm, gs, gsp = ops.dual_prior_pass2_backward(
+            y, means, scales, spatial, noise, _rows_ok(g_yhat) if g_yhat is not None else None,
+            _rows_ok(g_lik) if g_lik is not None else None)
+        return gy, gm, gs, gsp, None
+
+
+def dual_prior_pass2(y, means, scales, spatial, noise):
+    return _DualPriorPass2.apply(y, means, scales, spatial, noise)

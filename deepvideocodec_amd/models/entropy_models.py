@@ -129,13 +129,16 @@ class EntropyBottleneck(EntropyModel):
         self.register_buffer("target", torch.Tensor([-target, 0, target]))
 
     # -- parameters for the kernel: [C][58] raw values (softplus/tanh are applied on the GPU)
-    def packed_parameters(self) -> torch.Tensor:
+    def packed_parameters(self, differentiable: bool = False) -> torch.Tensor:
+        """(C, 58) raw parameters in the kernels' order: per layer matrix, bias, factor.  With
+        `differentiable` the concat stays on the autograd tape, so a gradient w.r.t. the packed
+        tensor reaches _matrix*/_bias*/_factor*."""
         parts = []
         for i in range(5):
-            parts.append(getattr(self, f"_matrix{i}").detach().reshape(self.channels, -1))
-            parts.append(getattr(self, f"_bias{i}").detach().reshape(self.channels, -1))
-            if i < 4:
-                parts.append(getattr(self, f"_factor{i}").detach().reshape(self.channels, -1))
+            names = (f"_matrix{i}", f"_bias{i}") + ((f"_factor{i}",) if i < 4 else ())
+            for nm in names:
+                p = getattr(self, nm)
+                parts.append((p if differentiable else p.detach()).reshape(self.channels, -1))
         packed = torch.cat(parts, dim=1).contiguous().float()
         assert packed.shape[1] == _lib.EB_PARAMS_PER_CHANNEL
         return packed
@@ -153,6 +156,9 @@ class EntropyBottleneck(EntropyModel):
         noise = None
         if training:
             noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(-0.5, 0.5)
+        if torch.is_grad_enabled() and noise is not None:
+            from .. import autograd as A
+            return A.eb_likelihood(x, self.packed_parameters(differentiable=True), self._medians_flat(), noise)
         out, lik, _ = ops.eb_forward(x, self.packed_parameters(), self._medians_flat(), noise=noise)
         return out, lik
 

@@ -435,3 +435,41 @@ def bilinear_up2_backward(grad_out: Tensor, h: int, w: int, scale: float = 1.0) 
     check(_lib.load().dvc_bilinear_up2_backward(C.byref(_src(grad_out)), C.byref(_dst(out)), n, h, w, float(scale),
                                                 _stream()), "dvc_bilinear_up2_backward")
     return out
+
+
+def eb_backward(x_eval: Tensor, packed: Tensor, grad_lik: Tensor, want_gx: bool = True):
+    """-> (grad wrt x_eval | None, grad wrt the raw packed parameters (C, 58))."""
+    n, c, h, w = x_eval.shape
+    lib = _lib.load()
+    gx = torch.empty((n, c, h, w), dtype=torch.float32, device=x_eval.device) if want_gx else None
+    scratch = torch.empty(lib.dvc_eb_backward_scratch_floats(c), dtype=torch.float32, device=x_eval.device)
+    gp = torch.empty((c, _lib.EB_PARAMS_PER_CHANNEL), dtype=torch.float32, device=x_eval.device)
+    check(lib.dvc_eb_backward(C.byref(_src(x_eval, "x_eval")), packed.data_ptr(), C.byref(_src(grad_lik, "grad_lik")),
+                              C.byref(_dst(gx)) if gx is not None else None, scratch.data_ptr(), gp.data_ptr(),
+                              n, h, w, _stream()), "dvc_eb_backward")
+    return gx, gp
+
+
+def dual_prior_pass1_backward(grad_yhat1: Tensor) -> Tensor:
+    n, c, h, w = grad_yhat1.shape
+    gy = torch.empty((n, c, h, w), dtype=torch.float32, device=grad_yhat1.device)
+    check(_lib.load().dvc_dual_prior_pass1_backward(C.byref(_src(grad_yhat1)), C.byref(_dst(gy)), n, h, w, _stream()),
+          "dvc_dual_prior_pass1_backward")
+    return gy
+
+
+def dual_prior_pass2_backward(y: Tensor, means: Tensor, scales: Tensor, spatial: Tensor, noise: Optional[Tensor],
+                              grad_yhat: Optional[Tensor], grad_lik: Optional[Tensor]):
+    n, c, h, w = y.shape
+    dev = y.device
+    gy = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+    gm = torch.empty_like(gy)
+    gs = torch.empty_like(gy)
+    gsp = torch.empty((n, 2 * c, h, w), dtype=torch.float32, device=dev)
+    gyh = C.byref(_src(grad_yhat, "grad_yhat")) if grad_yhat is not None else None
+    gl = C.byref(_src(grad_lik, "grad_lik")) if grad_lik is not None else None
+    check(_lib.load().dvc_dual_prior_pass2_backward(
+        C.byref(_src(y, "y")), C.byref(_src(means, "means")), C.byref(_src(scales, "scales")),
+        C.byref(_src(spatial, "spatial")), _ptr(noise), gyh, gl, C.byref(_dst(gy)), C.byref(_dst(gm)),
+        C.byref(_dst(gs)), C.byref(_dst(gsp)), n, h, w, _stream()), "dvc_dual_prior_pass2_backward")
+    return gy, gm, gs, gsp

@@ -263,6 +263,29 @@ int dvc_bilinear_up2_backward(const DvcSrc* grad_out, const DvcDst* grad_in, int
                               int32_t h, int32_t w, float scale, void* stream);
 
 /*
+ * Gradient of dvc_eb_forward's likelihood (compressai EntropyBottleneck._likelihood +
+ * LowerBound(1e-9)): x_eval = the tensor the likelihood was evaluated at (dvc_eb_forward's z_hat
+ * output: z + noise in training).  grad_x may be NULL.  grad_packed is (C, 58), the gradient
+ * w.r.t. the RAW packed parameters (softplus / tanh derivatives applied).  Deterministic.
+ */
+int64_t dvc_eb_backward_scratch_floats(int32_t channels);
+int dvc_eb_backward(const DvcSrc* x_eval, const float* packed_params, const DvcSrc* grad_lik,
+                    const DvcDst* grad_x, float* scratch, float* grad_packed, int32_t batch,
+                    int32_t h, int32_t w, void* stream);
+/* Adjoints of dvc_dual_prior_pass1 / pass2 (video_model.py:152-216 under autograd; round() is
+ * the straight-through identity of utils.py:149-152, so y_hat passes its gradient to y only).
+ * pass2: grad_yhat / grad_lik may be NULL; all four destinations are written in full (zeros at
+ * the sites a tensor does not feed): grad_means / grad_scales at first-pass sites, grad_spatial
+ * (2C channels) at second-pass sites. */
+int dvc_dual_prior_pass1_backward(const DvcSrc* grad_yhat1, const DvcDst* grad_y, int32_t batch,
+                                  int32_t h, int32_t w, void* stream);
+int dvc_dual_prior_pass2_backward(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales,
+                                  const DvcSrc* spatial, const float* noise, const DvcSrc* grad_yhat,
+                                  const DvcSrc* grad_lik, const DvcDst* grad_y, const DvcDst* grad_means,
+                                  const DvcDst* grad_scales, const DvcDst* grad_spatial, int32_t batch,
+                                  int32_t h, int32_t w, void* stream);
+
+/*
  * Host range coder (no GPU involved): restates compressai.ans
  * RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as used at
  * video_model.py:238-239,250-251,257,273,283.  64-bit-state rANS, 32-bit words,

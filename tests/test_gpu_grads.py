@@ -156,3 +156,119 @@ def test_pool_and_upsample_gradients():
         close(y, y_ref.detach(), what=name + " forward")
         (y * dev(R)).sum().backward()
         close(dx.grad, cx.grad, what=name + " grad")
+
+
+def test_factorized_prior_gradients():
+    """Likelihood of z + noise w.r.t. z and all 58 parameters per channel, against the oracle's
+    torch restatement of compressai's EntropyBottleneck under CPU autograd."""
+    from deepvideocodec_amd.models.entropy_models import EntropyBottleneck
+    from oracle import entropy_oracle as EO
+    torch.manual_seed(0)
+    C_ = 6
+    ref = EO.EntropyBottleneck(C_)
+    with torch.no_grad():   # move the parameters off their symmetric init
+        for p in ref.parameters():
+            p.add_(torch.randn_like(p) * 0.2)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(2, C_, 5, 7, generator=g) * 3
+    noise = torch.rand(z.shape, generator=g) - 0.5
+    R = torch.randn(z.shape, generator=g)
+
+    cz = z.clone().requires_grad_()
+    vals = (cz + noise).permute(1, 0, 2, 3).reshape(C_, 1, -1)
+    lik = EO.lower_bound(ref._likelihood(vals), 1e-9).reshape(C_, 2, 5, 7).permute(1, 0, 2, 3)
+    (-(torch.log2(lik)) * R).sum().backward()
+
+    net = EntropyBottleneck(C_)
+    net.load_state_dict(ref.state_dict())
+    net = net.cuda().train()
+    dz = dev(z).requires_grad_()
+    from deepvideocodec_amd import autograd as A
+    out, dlik = A.eb_likelihood(dz, net.packed_parameters(differentiable=True), net._medians_flat(), dev(noise))
+    close(dlik, lik.detach(), what="likelihood")
+    close(out, (z + noise), what="outputs")
+    (-(torch.log2(dlik)) * dev(R)).sum().backward()
+    close(dz.grad, cz.grad, what="grad z")
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if name == "quantiles":
+            continue
+        close(p.grad, q.grad, rel=5e-4, what=f"grad {name}")
+
+
+def _dual_prior_reference(y, means, scales, spatial_fn, noise):
+    """reference video_model.py:160-232 with explicit noise (torch ops, STE round)."""
+    from oracle import entropy_oracle as EO
+    n, c, h, w = y.shape
+    ii = torch.arange(h).view(h, 1)
+    jj = torch.arange(w).view(1, w)
+    m0 = (((ii + jj) % 2) == 0).float().view(1, 1, h, w)
+    m1 = 1.0 - m0
+
+    def ste(x):
+        return (torch.round(x) - x).detach() + x
+
+    def proc(y_, mu, sg, m):
+        mh, sh = mu * m, sg * m
+        return ste((y_ - mh) * m) + mh, mh, sh
+
+    y0, y1 = y.chunk(2, 1)
+    mu0, mu1 = means.chunk(2, 1)
+    s0, s1 = scales.chunk(2, 1)
+    yh00, mh00, sh00 = proc(y0, mu0, s0, m0)
+    yh11, mh11, sh11 = proc(y1, mu1, s1, m1)
+    spatial = spatial_fn(torch.cat((yh00, yh11, means, scales), 1))
+    a0, b0, a1, b1 = spatial.chunk(4, 1)
+    yh01, mh01, sh01 = proc(y0, a0, b0, m1)
+    yh10, mh10, sh10 = proc(y1, a1, b1, m0)
+    y_hat = torch.cat((yh00 + yh01, yh11 + yh10), 1)
+    means_hat = torch.cat((mh00 + mh01, mh11 + mh10), 1)
+    scales_hat = torch.cat((sh00 + sh01, sh11 + sh10), 1)
+    gc = EO.GaussianConditional(None)
+    lik = EO.lower_bound(gc._likelihood(y + noise, scales_hat, means_hat), 1e-9)
+    return y_hat, lik
+
+
+def test_dual_prior_gradients():
+    from deepvideocodec_amd import autograd as A
+    g = torch.Generator().manual_seed(7)
+    n, c, h, w = 2, 8, 6, 10
+    y = torch.randn(n, c, h, w, generator=g) * 4
+    means = torch.randn(n, c, h, w, generator=g)
+    scales = torch.randn(n, c, h, w, generator=g) * 0.8 + 0.5      # some below the .11 bound
+    wsp = torch.randn(2 * c, 3 * c, 3, 3, generator=g) / 10
+    bsp = torch.randn(2 * c, generator=g) * 0.3 + 0.4
+    noise = torch.rand(n, c, h, w, generator=g) - 0.5
+    R1 = torch.randn(n, c, h, w, generator=g)
+    R2 = torch.randn(n, c, h, w, generator=g)
+
+    cpu = [t.clone().requires_grad_() for t in (y, means, scales, wsp, bsp)]
+    yh, lik = _dual_prior_reference(cpu[0], cpu[1], cpu[2], lambda t: F.conv2d(t, cpu[3], cpu[4], padding=1), noise)
+    ((yh * R1).sum() + (-(torch.log2(lik)) * R2).sum()).backward()
+
+    d = [dev(t).requires_grad_() for t in (y, means, scales, wsp, bsp)]
+    yhat1 = A.dual_prior_pass1(d[0], d[1], d[2])
+    spatial = A.conv2d((yhat1, d[1], d[2]), d[3], d[4])
+    dyh, dlik = A.dual_prior_pass2(d[0], d[1], d[2], spatial, dev(noise))
+    close(dyh, yh.detach(), what="y_hat")
+    close(dlik, lik.detach(), rel=1e-4, what="likelihood")
+    ((dyh * dev(R1)).sum() + (-(torch.log2(dlik)) * dev(R2)).sum()).backward()
+    for name, a, b in zip(("y", "means", "scales", "w_spatial", "b_spatial"), d, cpu):
+        close(a.grad, b.grad, rel=1e-3, what=f"grad {name}")
+
+
+def test_se_gate_gradients():
+    from deepvideocodec_amd import autograd as A
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 32, 9, 13, generator=g)
+    fc1 = torch.randn(2, 32, generator=g) / 4
+    fc2 = torch.randn(32, 2, generator=g)
+    R = torch.randn(2, 32, generator=g)
+    c = [t.clone().requires_grad_() for t in (x, fc1, fc2)]
+    gate = torch.sigmoid(torch.relu(c[0].mean(dim=(-1, -2)) @ c[1].t()) @ c[2].t())
+    (gate * R).sum().backward()
+    d = [dev(t).requires_grad_() for t in (x, fc1, fc2)]
+    dg = A.se_gate(d[0], d[1], d[2])
+    close(dg.view(2, 32), gate.detach(), what="gate")
+    (dg.view(2, 32) * dev(R)).sum().backward()
+    for name, a, b in zip(("x", "fc1", "fc2"), d, c):
+        close(a.grad, b.grad, what=f"grad {name}")
