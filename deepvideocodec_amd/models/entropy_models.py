@@ -42,6 +42,16 @@ def _quantized_cdf_table(pmf: torch.Tensor, tail_mass: torch.Tensor, pmf_length:
     return torch.from_numpy(cdf)
 
 
+_noise_hook = None   # tests: callable(shape, device) -> tensor used instead of the random draw
+
+
+def uniform_noise(shape, device) -> torch.Tensor:
+    """U(-1/2, 1/2) quantisation noise of the training path (compressai's "noise" mode)."""
+    if _noise_hook is not None:
+        return _noise_hook(tuple(shape), device)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device).uniform_(-0.5, 0.5)
+
+
 class _CoderTables:
     """Contiguous host copies of the CDF tables for the range coder."""
 
@@ -155,7 +165,7 @@ class EntropyBottleneck(EntropyModel):
             training = self.training
         noise = None
         if training:
-            noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(-0.5, 0.5)
+            noise = uniform_noise(x.shape, x.device)
         if torch.is_grad_enabled() and noise is not None:
             from .. import autograd as A
             return A.eb_likelihood(x, self.packed_parameters(differentiable=True), self._medians_flat(), noise)
@@ -263,7 +273,7 @@ class GaussianConditional(EntropyModel):
         n, c, h, w = inputs.shape
         noise = None
         if training:
-            noise = torch.empty(inputs.shape, dtype=torch.float32, device=inputs.device).uniform_(-0.5, 0.5)
+            noise = uniform_noise(inputs.shape, inputs.device)
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=inputs.device)
         lik = torch.empty_like(out)
         mp = C.byref(ops._src(means, "means")) if means is not None else None

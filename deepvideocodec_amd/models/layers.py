@@ -14,6 +14,7 @@ from typing import Optional, Sequence, Tuple, Union
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import ops
 
 Tensor = torch.Tensor
@@ -48,6 +49,13 @@ class Conv2d(nn.Module):
 
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
                 pixel_shuffle=False, out=None) -> Tensor:
+        if torch.is_grad_enabled():
+            # training path: same forward kernel, on the autograd tape (residual adds un-fused)
+            if out is not None:
+                raise ValueError("Conv2d: `out=` is an inference-only option (call under torch.no_grad())")
+            return A.conv2d(x, self.weight, self.bias, stride=self.stride, in_slope=in_slope, out_slope=out_slope,
+                            residual=residual, res_scale=res_scale, residual2=residual2,
+                            pixel_shuffle=pixel_shuffle, packed=self.packed_weight())
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
                           pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight())
@@ -167,6 +175,8 @@ class SELayer(nn.Module):
         self.fc = Indexed(_0=lin1, _2=lin2)  # parameter names fc.0.weight / fc.2.weight
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.is_grad_enabled():
+            return A.se_gate(x, self.fc[0].weight, self.fc[2].weight)
         return ops.se_gate(x, self.fc[0].weight.detach(), self.fc[2].weight.detach())
 
 
@@ -203,9 +213,10 @@ class UNet(nn.Module):
         self.up_conv2 = ConvBlockResidual(ch_in=64, ch_out=out_ch)
 
     def forward(self, x: Tensor) -> Tensor:
+        pool = A.max_pool2 if torch.is_grad_enabled() else ops.max_pool2
         x1 = self.conv1(x)
-        x2 = self.conv2(ops.max_pool2(x1))
-        x3 = self.conv3(ops.max_pool2(x2))
+        x2 = self.conv2(pool(x1))
+        x3 = self.conv3(pool(x2))
         for i in range(4):
             x3 = self.context_refine[i](x3)
         d3 = self.up_conv3((x2, self.up3(x3)))
@@ -224,7 +235,7 @@ class MEBasic(nn.Module):
         self.conv4 = Conv2d(32, 16, 7)
         self.conv5 = Conv2d(16, 2, 7)
 
-    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Srcs, residual: Optional[Tensor] = None) -> Tensor:
         x = self.conv1(x, out_slope=0.0)
         x = self.conv2(x, out_slope=0.0)
         x = self.conv3(x, out_slope=0.0)
@@ -244,32 +255,42 @@ class ME_Spynet(nn.Module):
     def forward(self, im1: Tensor, im2: Tensor) -> Tensor:
         if im1.size(2) % 16 or im1.size(3) % 16:
             raise ValueError("ME_Spynet needs H and W to be multiples of 16")
+        grad = torch.is_grad_enabled()
+        pool = A.avg_pool2 if grad else ops.avg_pool2
         im1_list, im2_list = [im1], [im2]
         for level in range(self.L - 1):
-            im1_list.append(ops.avg_pool2(im1_list[level]))
-            im2_list.append(ops.avg_pool2(im2_list[level]))
+            im1_list.append(pool(im1_list[level]))
+            im2_list.append(pool(im2_list[level]))
         flow = None
         for level in range(self.L):
             k = self.L - 1 - level
-            inp = ops.spynet_level_input(im1_list[k], im2_list[k], flow)
-            flow = self.moduleBasic[level](inp, residual=inp[:, 6:8])
+            if grad:
+                # the fused level-input kernel, taken apart into its differentiable pieces
+                n, _, h, w = im1_list[k].shape
+                flow_up = (A.bilinear_up2(flow, 2.0) if flow is not None else
+                           torch.zeros((n, 2, h, w), dtype=torch.float32, device=im1.device))
+                warped = A.flow_warp(im2_list[k], flow_up)
+                flow = self.moduleBasic[level]((im1_list[k], warped, flow_up), residual=flow_up)
+            else:
+                inp = ops.spynet_level_input(im1_list[k], im2_list[k], flow)
+                flow = self.moduleBasic[level](inp, residual=inp[:, 6:8])
         return flow
 
 
 def flow_warp(im: Tensor, flow: Tensor) -> Tensor:
     """reference: layers.py:175-198."""
-    return ops.flow_warp(im, flow)
+    return A.flow_warp(im, flow) if torch.is_grad_enabled() else ops.flow_warp(im, flow)
 
 
 def bilineardownsacling(x: Tensor, scale: float = 1.0) -> Tensor:
     """reference: layers.py:201-206 (x0.5 bilinear == 2x2 mean for even sizes); `scale` folds the
     caller's division (video_model.py:499-500)."""
-    return ops.avg_pool2(x, scale)
+    return A.avg_pool2(x, scale) if torch.is_grad_enabled() else ops.avg_pool2(x, scale)
 
 
 def bilinearupsacling(x: Tensor, scale: float = 1.0) -> Tensor:
     """reference: layers.py:209-214."""
-    return ops.bilinear_up2(x, scale)
+    return A.bilinear_up2(x, scale) if torch.is_grad_enabled() else ops.bilinear_up2(x, scale)
 
 
 class MotionEncoder(Indexed):

@@ -5,8 +5,11 @@ method signatures and return structures.  The tensor work is done by the HIP ker
 of libdvc_hip.so through `deepvideocodec_amd.ops`; torch only carries device memory.
 
 Differences from the reference that a caller can observe (all documented in DESIGN.md):
-  * forward()/encode_inter()/decode_inter() run without autograd (inference + rate
-    estimation); a tensor on the CPU is rejected instead of silently taking a CPU path.
+  * a tensor on the CPU is rejected instead of silently taking a CPU path.
+  * forward() / forward_inter() are differentiable when torch's grad mode is on (the training
+    path: same forward kernels on the autograd tape, gradient kernels behind them); under
+    torch.no_grad() they take the fused inference launches.  encode_inter()/decode_inter()
+    never record a tape.
   * compress() does not round-trip z through the range coder to obtain z_hat
     (reference: video_model.py:238-239): z_hat = round(z - median) + median is what that
     round trip returns, so it is computed on the GPU while the host codes the bytes.
@@ -19,9 +22,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import autograd as A
 from .. import ops
 from .base_model import CompressionModel, get_scale_table
-from .entropy_models import GaussianConditional
+from .entropy_models import GaussianConditional, uniform_noise
 from .layers import (ConvStack3, Conv2d, Indexed, ME_Spynet, ResBlock, UNet, bilineardownsacling, flow_warp,
                      get_enc_dec_models, get_hyper_enc_dec_models, subpel_conv3x3)
 from .utils import resize_registered_buffers
@@ -94,6 +98,10 @@ class ContextualEncoder(nn.Module):
         n, _, h, w = x.shape
         # the bottleneck ResBlocks need their concatenated input as one tensor (it is also the
         # skip): the producer conv writes its half in place, the context half is copied in.
+        if torch.is_grad_enabled():   # training path: the concat is a differentiable copy
+            cat1 = torch.cat((self.conv1((x, context1)), context2), 1)
+            cat2 = torch.cat((self.conv2(self.res1(cat1)), context3), 1)
+            return self.conv4(self.conv3(self.res2(cat2)))
         cat1 = torch.empty((n, 2 * N, h // 2, w // 2), dtype=torch.float32, device=x.device)
         self.conv1((x, context1), out=cat1[:, :N])
         ops.copy_into(context2, cat1[:, N:])
@@ -121,6 +129,10 @@ class ContextualDecoder(nn.Module):
         N = self.N
         n, _, h, w = x.shape
         feature = self.up1(x)
+        if torch.is_grad_enabled():
+            feature = self.res1(torch.cat((self.up2(feature), context3), 1))
+            feature = self.res2(torch.cat((self.up3(feature), context2), 1))
+            return self.up4(feature)
         cat1 = torch.empty((n, 2 * N, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
         self.up2(feature, out=cat1[:, :N])
         ops.copy_into(context3, cat1[:, N:])
@@ -206,19 +218,26 @@ class _DualPriorContextModel(CompressionModel):
         return t.float().contiguous()
 
     def _forward(self, y, y_ref, context):
+        grad = torch.is_grad_enabled()
+        eb = self.entropy_bottleneck
         z = self.hyper_encoder(y)
-        z_hat_or_noisy, z_likelihoods = self.entropy_bottleneck(z)
+        z_hat_or_noisy, z_likelihoods = eb(z)
         if self.training:  # the rate sees z + noise, the decoder path round-STE(z) (video_model.py:220-224)
-            z_hat, _, _ = ops.eb_forward(z, self.entropy_bottleneck.packed_parameters(),
-                                         self.entropy_bottleneck._medians_flat(), want_likelihood=False)
+            if grad:
+                z_hat = A.round_ste(z, eb.packed_parameters(), eb._medians_flat())
+            else:
+                z_hat, _, _ = ops.eb_forward(z, eb.packed_parameters(), eb._medians_flat(), want_likelihood=False)
         else:
             z_hat = z_hat_or_noisy
         means, scales = self._prior_params(z_hat, y_ref, context)
-        yhat1 = ops.dual_prior_pass1(y, means, scales)
+        yhat1 = A.dual_prior_pass1(y, means, scales) if grad else ops.dual_prior_pass1(y, means, scales)
         spatial = self.y_spatial_prior((yhat1, means, scales))
         noise = None
         if self.training:
-            noise = torch.empty(y.shape, dtype=torch.float32, device=y.device).uniform_(-0.5, 0.5)
+            noise = uniform_noise(y.shape, y.device)
+        if grad:
+            y_hat, y_likelihoods = A.dual_prior_pass2(y, means, scales, spatial, noise)
+            return y_hat, {"y": y_likelihoods, "z": z_likelihoods}
         r = ops.dual_prior_pass2(y, means, scales, spatial, noise=noise, want=("y_hat", "likelihood"))
         return r["y_hat"], {"y": r["likelihood"], "z": z_likelihoods}
 
@@ -271,7 +290,6 @@ class MotionContextModel(_DualPriorContextModel):
             y_ref = self._zeros_ref(z_hat)
         return self.y_prior_fusion((params, y_ref)).chunk(2, 1)
 
-    @torch.no_grad()
     def forward(self, y, y_ref):
         return self._forward(y, y_ref, None)
 
@@ -305,7 +323,6 @@ class FrameContextModel(_DualPriorContextModel):
         temporal = self.temporal_prior_encoder[2](t)
         return self.y_prior_fusion((temporal, params, y_ref)).chunk(2, 1)
 
-    @torch.no_grad()
     def forward(self, y, y_ref, context):
         return self._forward(y, y_ref, context)
 
@@ -364,7 +381,6 @@ class DMC(nn.Module):
         return context1, context2, context3, warpframe
 
     # ---- training / evaluation forward ----------------------------------------------------
-    @torch.no_grad()
     def forward(self, frames, motion_pretrain=False, frame_pretrain=False):
         if not isinstance(frames, List):
             raise RuntimeError(f"Invalid number of frames: {len(frames)}.")
@@ -386,7 +402,6 @@ class DMC(nn.Module):
                            "feature_ref": context["feature_ref"], "x_ref": x_rec}
         return {"x_hat": reconstructions, "likelihoods": frames_likelihoods}
 
-    @torch.no_grad()
     def forward_inter(self, x_cur, dpb, motion_pretrain=False, frame_pretrain=False):
         x_ref = dpb["x_ref"]
         mv = self.optic_flow(x_cur, x_ref)

@@ -17,6 +17,13 @@ PSNR_TOL = 1e-3
 BPP_TOL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These are the evaluation-loop tests: like dmc/test.py they run under torch.no_grad()."""
+    with torch.no_grad():
+        yield
+
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 

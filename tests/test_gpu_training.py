@@ -1,0 +1,156 @@
+"""Training path: DMC.forward in train() mode under autograd (the call pattern of
+dmc/train.py:299-336: out = net(frames); loss = rate + lambda * distortion; loss.backward();
+aux_loss.backward()) against the CPU oracle under torch.autograd, with the quantisation noise
+of both sides replaced by one shared sequence."""
+import types
+
+import pytest
+import torch
+
+from oracle import dmc_oracle as O
+from oracle import entropy_oracle as EO
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss(out, frames, n_pix):
+    bits = sum((-torch.log2(t)).sum() for lk in out["likelihoods"] for v in lk.values() for t in v.values())
+    mse = sum(((x - r) ** 2).mean() for x, r in zip(frames[1:], out["x_hat"]))
+    return bits / n_pix + 100.0 * mse
+
+
+def _shared_noise(seed):
+    """call k of either side gets the same U(-.5,.5) tensor (generated on the CPU in NCHW)."""
+    state = {"k": 0}
+
+    def draw(shape):
+        g = torch.Generator().manual_seed(seed * 1000 + state["k"])
+        state["k"] += 1
+        return torch.rand(tuple(shape), generator=g) - 0.5
+    return state, draw
+
+
+def _oracle_with_noise(sd, draw):
+    ent = O.EntropyState(sd, training=True)
+    for key in ent.eb:
+        eb, gc = ent.eb[key], ent.gc[key]
+
+        def eb_forward(self, x, training=None):
+            n, c, h, w = x.shape
+            out = x + draw(x.shape)
+            vals = out.permute(1, 0, 2, 3).reshape(c, 1, -1)
+            lik = EO.lower_bound(self._likelihood(vals), 1e-9).reshape(c, n, h, w).permute(1, 0, 2, 3)
+            return out, lik
+
+        def gc_forward(self, inputs, scales, means=None, training=None):
+            out = inputs + draw(inputs.shape)
+            return out, EO.lower_bound(self._likelihood(out, scales, means), 1e-9)
+
+        eb.forward = types.MethodType(eb_forward, eb)
+        gc.forward = types.MethodType(gc_forward, gc)
+    return ent
+
+
+@pytest.mark.timeout(600)
+def test_training_step_gradients_match_oracle(seeded_sd):
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.models import entropy_models as EM
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = synthetic_gop(3, 64, 64, seed=5)
+    n_pix = 64 * 64 * 2
+
+    # ---- oracle (CPU autograd)
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "entropy_bottleneck" not in k and
+              "gaussian_conditional" not in k else v.clone()) for k, v in seeded_sd.items()}
+    _, draw = _shared_noise(3)
+    ent = _oracle_with_noise(sd, draw)
+    torch.set_num_threads(8)
+    out_o = O.forward(sd, ent, frames)
+    loss_o = _loss(out_o, frames, n_pix)
+    loss_o.backward()
+
+    # ---- HIP path
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda().train()
+    _, draw2 = _shared_noise(3)
+    EM._noise_hook = lambda shape, device: draw2(shape).to(device)
+    try:
+        out_g = net([f.cuda() for f in frames])
+        loss_g = _loss(out_g, [f.cuda() for f in frames], n_pix)
+        loss_g.backward()
+        aux = net.aux_loss()
+    finally:
+        EM._noise_hook = None
+    assert isinstance(aux, list) and len(aux) == 2
+    sum(aux).backward()
+
+    assert abs(loss_g.item() - loss_o.item()) <= 2e-4 * abs(loss_o.item()), (loss_g.item(), loss_o.item())
+    for i in range(2):
+        d = (out_g["x_hat"][i].detach().cpu() - out_o["x_hat"][i].detach()).abs().max().item()
+        assert d < 2e-4, (i, d)
+
+    # Per-tensor comparison.  A handful of activations sit within rounding noise of a LeakyReLU
+    # kink or a rounding tie on one side only, which perturbs the gradients that pass through them,
+    # so the bar is: nearly all tensors agree to 1e-3 of their largest entry, none is off by more
+    # than 3 %, and the full gradient vectors are parallel to 1e-5.
+    errs, dot, nn_g, nn_o = [], 0.0, 0.0, 0.0
+    for name, p in net.named_parameters():
+        if name.endswith("quantiles"):
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+            continue
+        if "entropy_bottleneck" in name:
+            key, pn = name.split(".entropy_bottleneck.")
+            ref = dict(ent.eb[key].named_parameters())[pn].grad
+        else:
+            ref = sd[name].grad
+        assert p.grad is not None and ref is not None, name
+        got = p.grad.detach().cpu().double()
+        ref = ref.double()
+        scale = max(float(ref.abs().max()), 1e-12)
+        errs.append((float((got - ref).abs().max()) / scale, name))
+        dot += float((got * ref).sum())
+        nn_g += float((got * got).sum())
+        nn_o += float((ref * ref).sum())
+    errs.sort()
+    cos = dot / (nn_g ** 0.5 * nn_o ** 0.5)
+    print("tensors:", len(errs), "median rel err %.2e" % errs[len(errs) // 2][0], "p95 %.2e" % errs[int(len(errs) * 0.95)][0],
+          "worst", errs[-3:], "cosine", cos)
+    assert len(errs) > 300
+    assert errs[int(len(errs) * 0.9)][0] < 1e-3, errs[int(len(errs) * 0.9)]
+    assert errs[-1][0] < 3e-2, errs[-1]
+    assert cos > 1 - 1e-5, cos
+
+
+def test_training_mode_parameter_partition_and_step(seeded_sd):
+    """dmc/train.py:255-272 splits parameters into main / aux by the `.quantiles` suffix and steps two
+    optimizers; one step must move every main parameter and keep the outputs finite."""
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda().train()
+    main = {n: p for n, p in net.named_parameters() if not n.endswith(".quantiles") and p.requires_grad}
+    aux = {n: p for n, p in net.named_parameters() if n.endswith(".quantiles") and p.requires_grad}
+    assert len(aux) == 2 and len(main) + len(aux) == len(dict(net.named_parameters()))
+    opt = torch.optim.Adam(main.values(), lr=1e-4)
+    aux_opt = torch.optim.Adam(aux.values(), lr=1e-3)
+    frames = [f.cuda() for f in synthetic_gop(3, 64, 64, seed=6, batch=2)]
+    before = {n: p.detach().clone() for n, p in main.items()}
+    for _ in range(2):
+        opt.zero_grad()
+        aux_opt.zero_grad()
+        out = net(frames)
+        loss = _loss(out, frames, 64 * 64 * 2 * 2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(main.values(), 1.0)
+        opt.step()
+        sum(net.aux_loss()).backward()
+        aux_opt.step()
+        assert torch.isfinite(loss)
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in main.items())
+    assert moved == len(main), (moved, len(main))
+    with torch.no_grad():
+        net.eval()
+        out = net(frames)
+        assert all(torch.isfinite(t).all() for t in out["x_hat"])
