@@ -98,6 +98,8 @@ SIGNATURES = {
     "dvc_dual_prior_pass1_backward": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_dual_prior_pass2_backward": (C.c_int, [_SRC, _SRC, _SRC, _SRC, _P, _SRC, _SRC, _DST, _DST, _DST, _DST,
                                                 _i32, _i32, _i32, _P]),
+    "dvc_likelihood_bits_backward": (C.c_int, [_SRC, _P, _DST, _i32, _i32, _i32, _P]),
+    "dvc_sq_err_backward": (C.c_int, [_SRC, _SRC, _P, _DST, _i32, _i32, _i32, _P]),
     "dvc_rans_encode": (_i64, [_P, _P, _i64, _P, _i32, _i32, _P, _P, _P, _i64]),
     "dvc_rans_decode": (C.c_int, [_P, _i64, _P, _i64, _P, _i32, _i32, _P, _P, _P]),
     "dvc_pmf_to_quantized_cdf": (C.c_int, [_P, _i32, _i32, _P]),

@@ -277,3 +277,41 @@ class _DualPriorPass2(torch.autograd.Function):
 
 def dual_prior_pass2(y, means, scales, spatial, noise):
     return _DualPriorPass2.apply(y, means, scales, spatial, noise)
+
+
+class _LikelihoodBits(torch.autograd.Function):
+    """(N,) sum over (C, H, W) of -log2(likelihood): the rate term of dmc/train.py:83."""
+
+    @staticmethod
+    def forward(ctx, lik):
+        ctx.save_for_backward(lik)
+        return ops.likelihood_bits(lik)
+
+    @staticmethod
+    def backward(ctx, g):
+        (lik,) = ctx.saved_tensors
+        return ops.likelihood_bits_backward(lik, g.contiguous().float())
+
+
+def likelihood_bits(lik):
+    return _LikelihoodBits.apply(lik)
+
+
+class _SqErrSum(torch.autograd.Function):
+    """(N,) sum over (C, H, W) of (a - b)^2: the distortion term of dmc/train.py:114-143."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.sq_err_sum(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        ga = ops.sq_err_backward(a, b, g.contiguous().float()) if (need[0] or need[1]) else None
+        return (ga if need[0] else None), (-ga if need[1] else None)
+
+
+def sq_err_sum(a, b):
+    return _SqErrSum.apply(a, b)

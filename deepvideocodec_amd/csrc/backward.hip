@@ -303,6 +303,32 @@ __global__ __launch_bounds__(256) void bilinear_up2_backward_kernel(Src g, Dst o
   }
 }
 
+// ------------------------------------------------------------------ loss reductions' adjoints
+// bits[n] = sum -log2(lik[n])  =>  dlik = -g[n] / (ln 2 * lik)
+__global__ __launch_bounds__(256) void likelihood_bits_backward_kernel(Src lik, const float* gbits, Dst out, int batch,
+                                                                       int h, int w) {
+  const long long hw = (long long)h * w;
+  FOREACH((long long)batch * lik.c * hw) {
+    const long long pix = i % hw;
+    const long long q = i / hw;
+    const int c = (int)(q % lik.c), n = (int)(q / lik.c);
+    out.p[n * out.bs + c * out.cs + pix] = -gbits[n] / (0.69314718055994530942f * lik.p[n * lik.bs + c * lik.cs + pix]);
+  }
+}
+
+// sse[n] = sum (a - b)^2  =>  da = 2 g[n] (a - b)   (db = -da)
+__global__ __launch_bounds__(256) void sq_err_backward_kernel(Src a, Src b, const float* gsse, Dst out, int batch, int h,
+                                                              int w) {
+  const long long hw = (long long)h * w;
+  FOREACH((long long)batch * a.c * hw) {
+    const long long pix = i % hw;
+    const long long q = i / hw;
+    const int c = (int)(q % a.c), n = (int)(q / a.c);
+    out.p[n * out.bs + c * out.cs + pix] =
+        2.0f * gsse[n] * (a.p[n * a.bs + c * a.cs + pix] - b.p[n * b.bs + c * b.cs + pix]);
+  }
+}
+
 }  // namespace
 
 #define LAUNCH_1D(kernel, total, stream, ...) \
@@ -449,4 +475,28 @@ extern "C" int dvc_bilinear_up2_backward(const DvcSrc* grad_out, const DvcDst* g
   LAUNCH_1D(bilinear_up2_backward_kernel, (long long)batch * grad_out->channels * h * w, stream, mk(grad_out),
             mk(grad_in), batch, h, w, scale);
   return dvc::check_launch("bilinear_up2_backward_kernel");
+}
+
+extern "C" int dvc_likelihood_bits_backward(const DvcSrc* lik, const float* grad_bits, const DvcDst* grad_lik,
+                                            int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && grad_bits != nullptr, "dvc_likelihood_bits_backward: bad arguments");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(lik, plane, "dvc_likelihood_bits_backward");
+  CHECK_DST(grad_lik, plane, "dvc_likelihood_bits_backward");
+  LAUNCH_1D(likelihood_bits_backward_kernel, (long long)batch * lik->channels * plane, stream, mk(lik), grad_bits,
+            mk(grad_lik), batch, h, w);
+  return dvc::check_launch("likelihood_bits_backward_kernel");
+}
+
+extern "C" int dvc_sq_err_backward(const DvcSrc* a, const DvcSrc* b, const float* grad_sse, const DvcDst* grad_a,
+                                   int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && grad_sse != nullptr, "dvc_sq_err_backward: bad arguments");
+  const long long plane = (long long)h * w;
+  CHECK_SRC(a, plane, "dvc_sq_err_backward(a)");
+  CHECK_SRC(b, plane, "dvc_sq_err_backward(b)");
+  DVC_REQUIRE(a->channels == b->channels, "dvc_sq_err_backward: channel mismatch");
+  CHECK_DST(grad_a, plane, "dvc_sq_err_backward");
+  LAUNCH_1D(sq_err_backward_kernel, (long long)batch * a->channels * plane, stream, mk(a), mk(b), grad_sse, mk(grad_a),
+            batch, h, w);
+  return dvc::check_launch("sq_err_backward_kernel");
 }

@@ -473,3 +473,19 @@ def dual_prior_pass2_backward(y: Tensor, means: Tensor, scales: Tensor, spatial:
         C.byref(_src(spatial, "spatial")), _ptr(noise), gyh, gl, C.byref(_dst(gy)), C.byref(_dst(gm)),
         C.byref(_dst(gs)), C.byref(_dst(gsp)), n, h, w, _stream()), "dvc_dual_prior_pass2_backward")
     return gy, gm, gs, gsp
+
+
+def likelihood_bits_backward(lik: Tensor, grad_bits: Tensor) -> Tensor:
+    n, c, h, w = lik.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=lik.device)
+    check(_lib.load().dvc_likelihood_bits_backward(C.byref(_src(lik)), grad_bits.data_ptr(), C.byref(_dst(out)),
+                                                   n, h, w, _stream()), "dvc_likelihood_bits_backward")
+    return out
+
+
+def sq_err_backward(a: Tensor, b: Tensor, grad_sse: Tensor) -> Tensor:
+    n, c, h, w = a.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device)
+    check(_lib.load().dvc_sq_err_backward(C.byref(_src(a, "a")), C.byref(_src(b, "b")), grad_sse.data_ptr(),
+                                          C.byref(_dst(out)), n, h, w, _stream()), "dvc_sq_err_backward")
+    return out

@@ -285,6 +285,13 @@ int dvc_dual_prior_pass2_backward(const DvcSrc* y, const DvcSrc* means, const Dv
                                   const DvcDst* grad_scales, const DvcDst* grad_spatial, int32_t batch,
                                   int32_t h, int32_t w, void* stream);
 
+/* Adjoints of the loss reductions dvc_likelihood_bits / dvc_sq_err_sum (RateDistortionLoss,
+ * dmc/train.py:74-93,114-143): grad_lik = -grad_bits[n] / (ln2 * lik); grad_a = 2 grad_sse[n] (a - b). */
+int dvc_likelihood_bits_backward(const DvcSrc* lik, const float* grad_bits, const DvcDst* grad_lik,
+                                 int32_t batch, int32_t h, int32_t w, void* stream);
+int dvc_sq_err_backward(const DvcSrc* a, const DvcSrc* b, const float* grad_sse, const DvcDst* grad_a,
+                        int32_t batch, int32_t h, int32_t w, void* stream);
+
 /*
  * Host range coder (no GPU involved): restates compressai.ans
  * RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as used at

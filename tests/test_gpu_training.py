@@ -2,6 +2,7 @@
 dmc/train.py:299-336: out = net(frames); loss = rate + lambda * distortion; loss.backward();
 aux_loss.backward()) against the CPU oracle under torch.autograd, with the quantisation noise
 of both sides replaced by one shared sequence."""
+import math
 import types
 
 import pytest
@@ -154,3 +155,56 @@ def test_training_mode_parameter_partition_and_step(seeded_sd):
         net.eval()
         out = net(frames)
         assert all(torch.isfinite(t).all() for t in out["x_hat"])
+
+
+def test_rate_distortion_loss_on_device_matches_cpu():
+    from deepvideocodec_amd import train as TR
+    g = torch.Generator().manual_seed(4)
+    n, frames, h, w = 2, 2, 32, 48
+    x = [torch.rand(n, 3, h, w, generator=g) for _ in range(frames)]
+    xh = [(t + 0.05 * torch.randn(t.shape, generator=g)) for t in x]
+    liks = [{"motion": {"y": torch.rand(n, 8, 2, 3, generator=g) * 0.9 + 0.05},
+             "frame": {"y": torch.rand(n, 6, 2, 3, generator=g) * 0.9 + 0.05,
+                       "z": torch.rand(n, 4, 1, 1, generator=g) * 0.9 + 0.05}} for _ in range(frames)]
+
+    def run(device):
+        leaves = [t.clone().to(device).requires_grad_() for t in xh]
+        lk = [{a: {b: v.clone().to(device).requires_grad_() for b, v in d.items()} for a, d in fl.items()} for fl in liks]
+        res = TR.RateDistortionLoss(lmbda=256.0)({"x_hat": leaves, "likelihoods": lk}, [t.to(device) for t in x])
+        res["loss"].backward()
+        return res, leaves, lk
+
+    rc, lc, kc = run("cpu")
+    rg, lg, kg = run("cuda:0")
+    for k in ("loss", "mse_loss", "bpp_loss", "distortion"):
+        assert abs(rg[k].item() - rc[k].item()) <= 1e-5 * abs(rc[k].item()), k
+    for a, b in zip(lg, lc):
+        assert torch.allclose(a.grad.cpu(), b.grad, rtol=1e-4, atol=1e-9)
+    for fg, fc in zip(kg, kc):
+        for lab in fc:
+            for fld in fc[lab]:
+                assert torch.allclose(fg[lab][fld].grad.cpu(), fc[lab][fld].grad, rtol=1e-4, atol=1e-9)
+
+
+def test_train_step_stages(seeded_sd):
+    """dmc/train.py:292-337 at three stages of the schedule: only the motion branch learns during
+    motion pre-training; the full model learns in the joint stage; losses stay finite."""
+    from deepvideocodec_amd import train as TR
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda().train()
+    crit = TR.RateDistortionLoss(lmbda=2048.0)
+    opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
+    frames = [f.cuda() for f in synthetic_gop(3, 64, 64, seed=8, batch=2)]
+    w_frame = net.contextual_encoder.conv1.weight.detach().clone()
+    w_motion = net.motion_encoder[0].conv1.weight.detach().clone()
+    stats = TR.train_step(net, crit, frames, opt, aux_opt, clip_max_norm=1.0, epoch=0)
+    assert all(math.isfinite(v) for v in stats.values())
+    assert torch.equal(net.contextual_encoder.conv1.weight.detach(), w_frame)        # frame branch untouched
+    assert not torch.equal(net.motion_encoder[0].conv1.weight.detach(), w_motion)
+    for epoch in (25, 45, 45):
+        stats = TR.train_step(net, crit, frames, opt, aux_opt, clip_max_norm=1.0, epoch=epoch)
+        assert all(math.isfinite(v) for v in stats.values()), (epoch, stats)
+    assert not torch.equal(net.contextual_encoder.conv1.weight.detach(), w_frame)
