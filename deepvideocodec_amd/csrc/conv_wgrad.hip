@@ -5,12 +5,14 @@
 // As a GEMM this is [Cout x pixels] * [pixels x (Cin * taps)]: a small output and a very long
 // reduction.  One v_mfma_f32_32x32x2_f32 takes rows = 32 output channels, columns = 32 input
 // channels (at one tap), k = 2 horizontally adjacent output pixels (lane >> 5 picks which).
-// A workgroup (8 waves) owns a 64 x 64 (Cout x Cin) block of the result for all taps (7x7: one
-// tap row per workgroup, 7 workgroups in z); a wave keeps one 32 x 32 corner of it for every
-// tap in registers (9 accumulators for 3x3), waves 0-3 summing the even pixel pairs of each
-// tile and waves 4-7 the odd ones (two partial blocks per workgroup).  The pixel axis is cut into slabs: workgroup
-// `split` of a block walks the tiles split, split + S, ... and writes one partial block; a
-// second kernel adds the partials in a fixed order (deterministic, no atomics).
+// A workgroup (8 waves) owns a (32 MT) x (32 CT) block (Cout x Cin; MT, CT in {1, 2} by the
+// layer's channel counts) of the result for all taps (7x7: one tap row per workgroup, 7
+// workgroups in z).  A wave keeps one 32 x 32 corner of the block for every tap in registers
+// (9 accumulators for 3x3); the 8 / (MT CT) waves that share a corner take interleaved pixel
+// pairs of each tile and their sums are added through LDS, in a fixed order, when the workgroup
+// is done.  The pixel axis is cut into slabs: workgroup `split` of a block walks the tiles
+// split, split + S, ... and writes one partial block; a second kernel adds the partials in a
+// fixed order (deterministic, no atomics).
 //
 // Staging per pixel tile (TH x 32 output pixels): the matching halo tile of 64 input channels
 // and the gradient tile of 64 output channels go global -> registers (range-checked buffer
@@ -36,8 +38,10 @@ struct WgradArgs {
   float in_slope;     // LeakyReLU applied to x while staging (1 = none)
 };
 
-template <int KS, int S>
+template <int KS, int S, int MT, int CT>
 struct WGeo {
+  static constexpr int KG = 8 / (MT * CT);      // waves sharing one corner (pixel-pair interleave)
+  static constexpr int XCH = 32 * CT, GCH = 32 * MT;   // staged input / gradient channels
   static constexpr int KH = KS == 7 ? 1 : KS;   // tap rows per workgroup
   static constexpr int TAPS = KH * KS;
   static constexpr int TAPS_ALL = KS * KS;
@@ -47,25 +51,29 @@ struct WGeo {
   static constexpr int IH = (TH - 1) * SL + KH, IW = (TW - 1) * SL + KS;
   static constexpr int XE = IH * IW, XSTR = XE | 1, XSLOTS = (XE + 63) / 64;
   static constexpr int GE = TH * TW, GSTR = GE + 1;
-  static constexpr int LDS_BYTES = (64 * XSTR + 64 * GSTR) * 4;
+  static constexpr int STAGE_FLOATS = XCH * XSTR + GCH * GSTR;
+  static constexpr int RED_FLOATS = (KG - 1) * MT * CT * 1024;   // one tap's tiles of the other groups
+  static constexpr int LDS_BYTES = (STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS) * 4;
 };
 
-template <int KS, int S>
+template <int KS, int S, int MT, int CT>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
-  using G = WGeo<KS, S>;
+  using G = WGeo<KS, S, MT, CT>;
+  constexpr int KG = G::KG, XCH = G::XCH, GCH = G::GCH, XPW = XCH / 8, GPW = GCH / 8;   // channels staged per wave
   constexpr int TAPS = G::TAPS, TH = G::TH, SL = G::SL, GS = G::GS, IW = G::IW, XE = G::XE, XSTR = G::XSTR;
   constexpr int XSLOTS = G::XSLOTS, GE = G::GE, GSTR = G::GSTR, PAD = G::PAD, KH = G::KH;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const x_s = lds;                 // [64][XSTR]
-  float* const g_s = lds + 64 * XSTR;     // [64][GSTR]
+  float* const x_s = lds;                  // [XCH][XSTR]
+  float* const g_s = lds + XCH * XSTR;     // [GCH][GSTR]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                  // which half of the tile's pixel pairs this wave multiplies
-  const int mt = (wave >> 1) & 1, ct = wave & 1;
+  const int corner = wave % (MT * CT);        // which 32 x 32 corner of the block
+  const int grp = wave / (MT * CT);           // which interleave of the tile's pixel pairs
+  const int mt = corner / CT, ct = corner % CT;
   const int cob = blockIdx.y / a.n_cib, cib = blockIdx.y - cob * a.n_cib;
-  const int co0 = cob * 64, ci0 = cib * 64;
+  const int co0 = cob * GCH, ci0 = cib * XCH;
   const int ky0 = (KS == 7) ? (int)blockIdx.z : 0;
   const int nsplit = gridDim.x;
 
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
   const float in_slope = a.in_slope;
   const int per_n = a.tiles_x * a.tiles_y;
 
-  float xr[8][XSLOTS], gr[8];   // wave w stages channels 8 w .. 8 w + 7 of both tiles
+  float xr[XPW][XSLOTS], gr[GPW];   // wave w stages channels XPW w .. of x and GPW w .. of g
 
   auto prefetch = [&](int t) {
     const int n = t / per_n, r = t - n * per_n;
@@ -110,8 +118,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
       goff = ok ? 4u * (unsigned)(oy * a.wo + ox) : 0x80000000u;
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int ci = ci0 + 8 * wave + c;
+    for (int c = 0; c < XPW; ++c) {
+      const int ci = ci0 + XPW * wave + c;
       const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
       const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
       const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
@@ -129,8 +137,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < XSLOTS; ++j)
         xr[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[j], 0, 0));
-
-      const int co = co0 + 8 * wave + c;
+    }
+#pragma unroll
+    for (int c = 0; c < GPW; ++c) {
+      const int co = co0 + GPW * wave + c;
       const bool haveg = co < cout;
       const unsigned long long pg = reinterpret_cast<unsigned long long>(a.g) +
                                     4ull * (unsigned long long)(((long long)n * cout + (haveg ? co : 0)) * gplane);
@@ -145,13 +155,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 
   auto commit = [&]() {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float* xd = x_s + (8 * wave + c) * XSTR + lane;
+    for (int c = 0; c < XPW; ++c) {
+      float* xd = x_s + (XPW * wave + c) * XSTR + lane;
 #pragma unroll
       for (int j = 0; j < XSLOTS; ++j)
         if (64 * (j + 1) <= XE || lane + 64 * j < XE) xd[64 * j] = fmaxf(xr[c][j], xr[c][j] * in_slope);
-      if (GE == 64 || lane < GE) g_s[(8 * wave + c) * GSTR + lane] = gr[c];
     }
+#pragma unroll
+    for (int c = 0; c < GPW; ++c)
+      if (GE == 64 || lane < GE) g_s[(GPW * wave + c) * GSTR + lane] = gr[c];
   };
 
   f32x16 acc[TAPS];
@@ -162,6 +174,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 
   const float* const a_base = g_s + (mt * 32 + l32) * GSTR + half + 2 * grp;
   const float* const b_base = x_s + (ct * 32 + l32) * XSTR + (half + 2 * grp) * SL;
+  static_assert(32 % (2 * KG) == 0 && GE % (2 * KG) == 0, "pixel-pair interleave must tile a row");
 
   int t = blockIdx.x;
   if (t < a.n_tiles) {
@@ -173,8 +186,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     const int tn = t + nsplit;
     if (tn < a.n_tiles) prefetch(tn);
 #pragma unroll
-    for (int jj = 0; jj < GE / 4; ++jj) {   // this wave's pixel pairs: pixels 4 jj + 2 grp, + 1
-      const int row = (4 * jj) / 32, px = (4 * jj) % 32;
+    for (int jj = 0; jj < GE / (2 * KG); ++jj) {   // this wave's pixel pairs: pixels 2 KG jj + 2 grp, + 1
+      const int row = (2 * KG * jj) / 32, px = (2 * KG * jj) % 32;
       const float av = a_base[row * 32 + px];
 #pragma unroll
       for (int ky = 0; ky < KH; ++ky)
@@ -189,17 +202,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   }
 
-  // partial block: [split][tap][co][ci]; register r of a wave's tile is row (r&3) + 8 (r>>2) + 4 half
-  float* const pbase = a.partial + (long long)(2 * blockIdx.x + grp) * G::TAPS_ALL * a.cout_pad * a.cin_pad;
+  // Sum the KG waves that share a corner: per tap, groups 1 .. KG-1 park their tile in LDS and
+  // group 0 adds them in ascending order, then stores the tap of the partial block
+  // [split][tap][co][ci]; register r of a tile is row (r&3) + 8 (r>>2) + 4 half, column l32.
+  float* const red = lds;   // [KG-1][MT*CT][16][64]; the staging buffers are free after the last barrier
+  float* const pbase = a.partial + (long long)blockIdx.x * G::TAPS_ALL * a.cout_pad * a.cin_pad;
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp) {
-    const int tap_all = ky0 * KS + tp;   // 7x7: tp is kx of tap row ky0; otherwise ky0 = 0
-    float* const pt = pbase + (long long)tap_all * a.cout_pad * a.cin_pad + ci0 + ct * 32 + l32;
+    if (grp > 0) {
+      float* dst = red + ((grp - 1) * (MT * CT) + corner) * 1024 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      pt[(long long)co * a.cin_pad] = acc[tp][r];
+      for (int r = 0; r < 16; ++r) dst[64 * r] = acc[tp][r];
     }
+    __syncthreads();
+    if (grp == 0) {
+      f32x16 v = acc[tp];
+#pragma unroll
+      for (int k = 1; k < KG; ++k) {
+        const float* src = red + ((k - 1) * (MT * CT) + corner) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += src[64 * r];
+      }
+      const int tap_all = ky0 * KS + tp;   // 7x7: tp is kx of tap row ky0; otherwise ky0 = 0
+      float* const pt = pbase + (long long)tap_all * a.cout_pad * a.cin_pad + ci0 + ct * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        pt[(long long)co * a.cin_pad] = v[r];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 }
 
 struct Plan {
-  int ho, wo, th, tiles_x, tiles_y, n_tiles, cout_pad, cin_pad, n_cib, blocks, nsplit, taps;
+  int ho, wo, th, tiles_x, tiles_y, n_tiles, cout_pad, cin_pad, n_cib, blocks, nsplit, taps, mt, ct;
 };
 
 int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Plan* p, const char* who) {
@@ -238,25 +270,28 @@ int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Pl
   const long long nt = (long long)batch * p->tiles_x * p->tiles_y;
   DVC_REQUIRE(nt < (1LL << 30), "%s: too many tiles", who);
   p->n_tiles = (int)nt;
-  p->cout_pad = (cout + 63) / 64 * 64;
-  p->cin_pad = (cin + 63) / 64 * 64;
-  p->n_cib = p->cin_pad / 64;
-  p->blocks = (p->cout_pad / 64) * p->n_cib;
+  p->mt = cout > 32 ? 2 : 1;
+  p->ct = cin > 32 ? 2 : 1;
+  const int cob = 32 * p->mt, cib = 32 * p->ct;
+  p->cout_pad = (cout + cob - 1) / cob * cob;
+  p->cin_pad = (cin + cib - 1) / cib * cib;
+  p->n_cib = p->cin_pad / cib;
+  p->blocks = (p->cout_pad / cob) * p->n_cib;
   p->taps = ks * ks;
   const int wg_per_split = p->blocks * (ks == 7 ? 7 : 1);
-  int s = (512 + wg_per_split - 1) / wg_per_split;   // about two 8-wave workgroups per CU in total
+  int s = (256 + wg_per_split - 1) / wg_per_split;   // one 8-wave workgroup fits a CU: about one round of them
   if (s > p->n_tiles) s = p->n_tiles;
   if (s < 1) s = 1;
   p->nsplit = s;
   return DVC_OK;
 }
 
-template <int KS, int S>
+template <int KS, int S, int MT, int CT>
 int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
-  using G = WGeo<KS, S>;
+  using G = WGeo<KS, S, MT, CT>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, S>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, S, MT, CT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(wgrad %d,%d): %s", KS, S, hipGetErrorString(e));
@@ -265,8 +300,14 @@ int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.nsplit, p.blocks, KS == 7 ? 7 : 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS, S>), grid, dim3(512), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, MT, CT>), grid, dim3(512), G::LDS_BYTES, st, a);
   return dvc::check_launch("conv_wgrad_kernel");
+}
+
+template <int KS, int S>
+int launch_block(const WgradArgs& a, const Plan& p, hipStream_t st) {
+  if (p.mt == 2) return p.ct == 2 ? launch<KS, S, 2, 2>(a, p, st) : launch<KS, S, 2, 1>(a, p, st);
+  return p.ct == 2 ? launch<KS, S, 1, 2>(a, p, st) : launch<KS, S, 1, 1>(a, p, st);
 }
 
 }  // namespace
@@ -275,7 +316,7 @@ extern "C" int64_t dvc_conv2d_wgrad_scratch_floats(int32_t cout, int32_t cin, in
                                                    int32_t batch, int32_t in_h, int32_t in_w) {
   Plan p;
   if (make_plan(cout, cin, ksize, stride, batch, in_h, in_w, &p, "dvc_conv2d_wgrad_scratch_floats")) return DVC_EINVAL;
-  return (int64_t)2 * p.nsplit * p.taps * p.cout_pad * p.cin_pad;
+  return (int64_t)p.nsplit * p.taps * p.cout_pad * p.cin_pad;
 }
 
 extern "C" int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch, int32_t in_h, int32_t in_w,
@@ -316,12 +357,12 @@ extern "C" int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch
   a.in_slope = in_act ? in_slope : 1.0f;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
-  if (ksize == 3) rc = stride == 1 ? launch<3, 1>(a, p, st) : launch<3, 2>(a, p, st);
-  else if (ksize == 1) rc = stride == 1 ? launch<1, 1>(a, p, st) : launch<1, 2>(a, p, st);
-  else rc = launch<7, 1>(a, p, st);
+  if (ksize == 3) rc = stride == 1 ? launch_block<3, 1>(a, p, st) : launch_block<3, 2>(a, p, st);
+  else if (ksize == 1) rc = stride == 1 ? launch_block<1, 1>(a, p, st) : launch_block<1, 2>(a, p, st);
+  else rc = launch_block<7, 1>(a, p, st);
   if (rc) return rc;
   const long long total = (long long)out_channels * cin * p.taps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, st, scratch, grad_weight,
-                     2 * p.nsplit, p.taps, out_channels, cin, p.cout_pad, p.cin_pad);
+                     p.nsplit, p.taps, out_channels, cin, p.cout_pad, p.cin_pad);
   return dvc::check_launch("wgrad_reduce_kernel");
 }
