@@ -130,7 +130,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* lds4) {
 __global__ __launch_bounds__(256) void plane_dot_partial_kernel(Src a, Src b, int has_b, long long hw, float* partial) {
   __shared__ float red[4];
   const int slice = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
-  const long long per = (hw + SLICES - 1) / SLICES;
+  const int nslices = gridDim.x;   // <= SLICES, chosen by the host from the plane size
+  const long long per = (hw + nslices - 1) / nslices;
   const long long s0 = slice * per, s1 = s0 + per < hw ? s0 + per : hw;
   const float* pa = a.p + n * a.bs + c * a.cs;
   const float* pb = has_b ? b.p + n * b.bs + c * b.cs : nullptr;
@@ -138,25 +139,25 @@ __global__ __launch_bounds__(256) void plane_dot_partial_kernel(Src a, Src b, in
   if (has_b) for (long long i = s0 + threadIdx.x; i < s1; i += 256) s += pa[i] * pb[i];
   else for (long long i = s0 + threadIdx.x; i < s1; i += 256) s += pa[i];
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) partial[((long long)n * a.c + c) * SLICES + slice] = s;
+  if (threadIdx.x == 0) partial[((long long)n * a.c + c) * nslices + slice] = s;
 }
 
 // out[n*C + c] (sum_batch = 0) or out[c] = sum over n (sum_batch = 1), fixed order
 __global__ __launch_bounds__(256) void plane_dot_final_kernel(const float* partial, int batch, int channels,
-                                                              int sum_batch, float* out) {
+                                                              int sum_batch, int nslices, float* out) {
   const int total = sum_batch ? channels : batch * channels;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     float s = 0.f;
     if (sum_batch) {
       for (int n = 0; n < batch; ++n) {
-        const float* pp = partial + ((long long)n * channels + i) * SLICES;
+        const float* pp = partial + ((long long)n * channels + i) * nslices;
         float sn = 0.f;
-        for (int k = 0; k < SLICES; ++k) sn += pp[k];
+        for (int k = 0; k < nslices; ++k) sn += pp[k];
         s += sn;
       }
     } else {
-      const float* pp = partial + (long long)i * SLICES;
-      for (int k = 0; k < SLICES; ++k) s += pp[k];
+      const float* pp = partial + (long long)i * nslices;
+      for (int k = 0; k < nslices; ++k) s += pp[k];
     }
     out[i] = s;
   }
@@ -416,12 +417,16 @@ extern "C" int dvc_plane_dot(const DvcSrc* a, const DvcSrc* b, int32_t batch, in
     CHECK_SRC(b, plane, "dvc_plane_dot(b)");
     DVC_REQUIRE(b->channels == a->channels, "dvc_plane_dot: channel mismatch");
   }
-  hipLaunchKernelGGL(plane_dot_partial_kernel, dim3(SLICES, a->channels, batch), dim3(256), 0, (hipStream_t)stream,
+  // about 4096 elements per block, so that small planes are not shredded into tiny blocks
+  int nslices = (int)((plane + 4095) / 4096);
+  nslices = nslices < 1 ? 1 : (nslices > SLICES ? SLICES : nslices);
+  hipLaunchKernelGGL(plane_dot_partial_kernel, dim3(nslices, a->channels, batch), dim3(256), 0, (hipStream_t)stream,
                      mk(a), b ? mk(b) : Src{nullptr, 0, 0, 0}, b ? 1 : 0, plane, scratch);
   int rc = dvc::check_launch("plane_dot_partial_kernel");
   if (rc) return rc;
   const int total = sum_batch ? a->channels : batch * a->channels;
-  LAUNCH_1D(plane_dot_final_kernel, total, stream, (const float*)scratch, batch, a->channels, sum_batch ? 1 : 0, out);
+  LAUNCH_1D(plane_dot_final_kernel, total, stream, (const float*)scratch, batch, a->channels, sum_batch ? 1 : 0, nslices,
+            out);
   return dvc::check_launch("plane_dot_final_kernel");
 }
 
