@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
 template <int MT, int NT>
 constexpr int min_waves_per_simd() { return 2; }
 
-template <int KS, int S, int MT, int NT>
+// HALF: a 32-channel workgroup (MT = 1) working on one half of a 64-channel packed weight block,
+// used to double the number of workgroups of small launches whose weights are packed 64 wide.
+template <int KS, int S, int MT, int NT, bool HALF = false>
 struct Geo {
+  static_assert(!HALF || MT == 1, "half blocks are 32 channels");
   static constexpr int CK = chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
@@ -86,16 +89,18 @@ struct Geo {
   static constexpr int CHS = IH * IW;            // floats per staged channel
   static constexpr int TAPS = KS * KS;
   static constexpr int KCH = CK * TAPS;          // k values per chunk
-  static constexpr int SLAB = slab_floats(KS, S, CB);
+  static constexpr int CBP = HALF ? 64 : CB;     // output channels per packed weight row
+  static constexpr int SLAB = slab_floats(KS, S, CBP);
   static constexpr int IN_BUF = (CK * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
   static constexpr int LDS_BYTES = (2 * IN_BUF + 2 * SLAB) * 4;
 };
 
-template <int KS, int S, int MT, int NT>
+template <int KS, int S, int MT, int NT, bool HALF = false>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
-  using G = Geo<KS, S, MT, NT>;
+  using G = Geo<KS, S, MT, NT, HALF>;
+  constexpr int CBP = G::CBP;
   constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW;
   constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
 
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   }
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW;
-  const int cb0 = blockIdx.y * CB;
+  const int wblock = HALF ? (int)(blockIdx.y >> 1) : (int)blockIdx.y;   // packed weight block
+  const int cb0 = HALF ? wblock * 64 + (int)(blockIdx.y & 1) * 32 : wblock * CB;
+  if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
   const int n = blockIdx.z;
   const int nchunks = (a.cin + CK - 1) / CK;
 
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
   }
   const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
-  const float* wslabs = a.wpacked + (long long)blockIdx.y * nchunks * SLAB;
+  const float* wslabs = a.wpacked + (long long)wblock * nchunks * SLAB;
 
   float rin[CK][IN_PT];
 
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const int b_lane = half * CHS + (wave * NT * SL) * IW + l32 * SL;
-  const int a_lane = (half * TAPS) * CB + l32;
+  const int a_lane = (half * TAPS) * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
 
   // ---- prologue: chunk 0 into buffer 0
   dma_weights(0, 0);
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     auto fetch = [&](int t, int slot) {
       const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CB + mt * 32];
+      for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CBP + mt * 32];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
     };
@@ -458,12 +465,12 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   }
 }
 
-template <int KS, int S, int MT, int NT>
+template <int KS, int S, int MT, int NT, bool HALF = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
-  using G = Geo<KS, S, MT, NT>;
+  using G = Geo<KS, S, MT, NT, HALF>;
   static bool attr_set = false;   // LDS above the 64 KiB default needs the opt-in once per kernel
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
@@ -474,8 +481,8 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   ConvArgs b = a;
   const int tiles_y = (a.ho + G::TH - 1) / G::TH;
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
-  dim3 grid(b.tiles_x * tiles_y, (a.cout + G::CB - 1) / G::CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT>), grid, dim3(256), G::LDS_BYTES, st, b);
+  dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF>), grid, dim3(256), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
 }
 
@@ -499,6 +506,9 @@ int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   if (mt == 2) {
     if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 2, 4>(a, batch, st); }
     if (nt == 2) return launch<KS, S, 2, 2>(a, batch, st);
+    // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
+    const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
+    if (blocks < 384) return launch<KS, S, 1, 1, true>(a, batch, st);
     return launch<KS, S, 2, 1>(a, batch, st);
   }
   if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4>(a, batch, st); }
