@@ -41,20 +41,27 @@ def parse():
     ap.add_argument("--gop", type=int, default=12)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-scale", type=int, default=3, help="CPU sample is the frame downscaled by this factor per side")
+    ap.add_argument("--reuse", type=int, default=0,
+                    help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
+                         "not the headline configuration")
     ap.add_argument("--gops-in-flight", type=int, default=2,
                     help="independent GOPs coded concurrently per GPU (one host thread + HIP stream each); "
                          "a step codes this many GOPs per GPU")
     return ap.parse_args()
 
 
-def codec_gop(net, frames, clamp):
-    """dmc/test.py:162-196 for one GOP; returns (bytes, list of reconstructions)."""
+def codec_gop(net, frames, clamp, reuse=False):
+    """dmc/test.py:162-196 for one GOP; returns (bytes, list of reconstructions).  `reuse`: take the
+    reconstruction from the encoder pass instead of decoding the strings again (same outputs)."""
     dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
     nbytes = 0
     recs = []
     for x in frames[1:]:
-        enc = net.encode_inter(x, dpb)
-        rec, info = net.decode_inter(enc["strings"], enc["shape"], dpb)
+        if reuse:
+            enc, rec, info = net.encode_inter_with_recon(x, dpb)
+        else:
+            enc = net.encode_inter(x, dpb)
+            rec, info = net.decode_inter(enc["strings"], enc["shape"], dpb)
         rec = clamp(rec)
         dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"], "y_mv_ref": info["y_mv_ref"]}
         nbytes += sum(len(s[0]) for v in enc["strings"].values() for s in v)
@@ -235,7 +242,7 @@ def main():
         def work(g):
             torch.cuda.set_device(dev)
             with torch.cuda.stream(streams[g]):
-                b, recs = codec_gop(net, gops[s][g], clamp)
+                b, recs = codec_gop(net, gops[s][g], clamp, reuse=bool(args.reuse))
                 streams[g].synchronize()
             return b, recs
         res = list(pool.map(work, range(G))) if G > 1 else [work(0)]
@@ -309,7 +316,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DMC {args.height}x{args.width} (padded {pad64(args.height)}x{pad64(args.width)}) "
-                                   f"GOP={args.gop} encode_inter+decode_inter per P frame, batch=1 per GPU, "
+                                   f"GOP={args.gop} " + ("encode_inter_with_recon (encoder-side reuse)" if args.reuse
+                                                         else "encode_inter+decode_inter") + " per P frame, batch=1 per GPU, "
                                    f"seeded random-init weights (calibrated), {G} independent GOPs in flight per GPU "
                                    "(one host thread + stream each), one such group per step",
                        "gop": args.gop, "gops_per_step_per_gpu": G, "p_frames_per_step_per_gpu": n_p * G},

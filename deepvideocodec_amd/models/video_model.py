@@ -444,6 +444,37 @@ class DMC(nn.Module):
         }
 
     @torch.no_grad()
+    def encode_inter_with_recon(self, x_cur, dpb):
+        """encode_inter plus the decoder-side reconstruction, computed once: the reference's loop
+        (dmc/test.py:187-188) decodes right after encoding and so recomputes the motion decoder,
+        the motion compensation and the contexts from identical tensors.  Here the encoder's
+        quantised latents (bit-identical to what the range decoder returns) go straight through the
+        contextual decoder and the reconstruction net.  Returns (encode_inter's dict, x_rec,
+        decode_inter's info dict); x_rec / info equal decode_inter(strings, shape, dpb) exactly."""
+        mcm, fcm = self.motion_context_model, self.frame_context_model
+        mcm.gaussian_conditional.coder_tables(), fcm.gaussian_conditional.coder_tables()
+        mcm.entropy_bottleneck.coder_tables(), fcm.entropy_bottleneck.coder_tables()
+        mv = self.optic_flow(x_cur, dpb["x_ref"])
+        y_mv = self.motion_encoder(mv)
+        y_mv_hat, mv_pending = mcm._compress_device(y_mv, dpb["y_mv_ref"], None)
+        mv_pending.start_download()
+        mv_hat = self.motion_decoder(y_mv_hat)
+        context1, context2, context3, _ = self.motion_compensation(mv_hat, dpb)
+        y = self.contextual_encoder(x_cur, context1, context2, context3)
+        y_hat, frame_pending = fcm._compress_device(y, dpb["y_ref"], context3)
+        frame_pending.start_download()
+        x_rec_feature = self.contextual_decoder(y_hat, context2, context3)
+        feature, x_rec = self.recon_generation_net(x_rec_feature, context1)
+        torch.cuda.current_stream().synchronize()
+        mv_strings = mv_pending.encode()
+        frame_strings = frame_pending.encode()
+        enc = {
+            "strings": {"motion": mv_strings["strings"], "frame": frame_strings["strings"]},
+            "shape": {"motion": mv_strings["shape"], "frame": frame_strings["shape"]},
+        }
+        return enc, x_rec, {"x_ref": x_rec, "feature_ref": feature, "y_ref": y_hat, "y_mv_ref": y_mv_hat}
+
+    @torch.no_grad()
     def decode_inter(self, strings, shapes, dpb):
         """reference: video_model.py:601-614."""
         y_mv_hat = self.motion_context_model.decompress(strings["motion"], shapes["motion"], dpb["y_mv_ref"])

@@ -253,3 +253,21 @@ def test_evaluation_loop_bitstream_round_trip(gpu_net, seeded_sd, oracle_entropy
         evaluate.code_gop(Net(), frames_cpu[0:3], fd3, evaluate.RawIntra(), lambda t: t.clamp(0, 1))
     a, b = fd3.getvalue(), segs[0][1]
     assert a == b or abs(len(a) - len(b)) <= 0.02 * len(a)
+
+
+def test_encoder_side_reuse_equals_separate_decode(gpu_net):
+    """encode_inter_with_recon returns the same strings as encode_inter and exactly the
+    reconstruction / buffer entries decode_inter rebuilds from those strings, over a 3-frame chain."""
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = [f.cuda() for f in synthetic_gop(4, 128, 192, seed=17)]
+    dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    for x in frames[1:]:
+        enc = gpu_net.encode_inter(x, dpb)
+        rec, info = gpu_net.decode_inter(enc["strings"], enc["shape"], dpb)
+        enc2, rec2, info2 = gpu_net.encode_inter_with_recon(x, dpb)
+        assert enc2["strings"] == enc["strings"] and enc2["shape"] == enc["shape"]
+        assert torch.equal(rec2, rec)
+        for k in ("feature_ref", "y_ref", "y_mv_ref", "x_ref"):
+            assert torch.equal(info2[k], info[k]), k
+        dpb = {"x_ref": rec.clamp(0, 1), "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+               "y_mv_ref": info["y_mv_ref"]}
