@@ -271,3 +271,33 @@ def test_encoder_side_reuse_equals_separate_decode(gpu_net):
             assert torch.equal(info2[k], info[k]), k
         dpb = {"x_ref": rec.clamp(0, 1), "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
                "y_mv_ref": info["y_mv_ref"]}
+
+
+@pytest.mark.timeout(600)
+def test_config0_256x256_gop4_random_frames_vs_oracle(gpu_net, seeded_sd, oracle_entropy):
+    """BASELINE configs[0]: one 256x256 GOP of 4 uniformly random frames, forward + likelihood bpp,
+    HIP path against the CPU oracle frame by frame (teacher-forced from the oracle's buffer; a frame
+    whose only differences are genuine rounding ties is counted, not compared strictly)."""
+    from deepvideocodec_amd.testing import random_gop
+    frames = random_gop(4, 256, 256, seed=0)
+    n_pix = 256 * 256
+    dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    strict = 0
+    torch.set_num_threads(8)
+    for i in range(1, 4):
+        trace = {}
+        x_o, lik_o, ctx_o = O.forward_inter(seeded_sd, oracle_entropy, frames[i], dpb, trace=trace)
+        dpb_g = {k: (None if v is None else v.cuda()) for k, v in dpb.items()}
+        x_g, lik_g, ctx_g = gpu_net.forward_inter(frames[i].cuda(), dpb_g)
+        ok_m, n_m = _explained_by_ties(ctx_g["y_mv_ref"].cpu(), trace["motion_context_model"])
+        assert ok_m, f"frame {i}: {n_m} motion latents differ without a rounding tie"
+        ok_f, n_f = _explained_by_ties(ctx_g["y_ref"].cpu(), trace["frame_context_model"])
+        assert ok_f, f"frame {i}: {n_f} frame latents differ without a rounding tie"
+        if n_m == 0 and n_f == 0:
+            strict += 1
+            assert abs(psnr(frames[i], x_o) - psnr(frames[i], x_g.cpu())) <= PSNR_TOL, i
+            bw = sum(bits(t) for v in lik_o.values() for t in v.values()) / n_pix
+            bg = sum(bits(t.cpu()) for v in lik_g.values() for t in v.values()) / n_pix
+            assert abs(bw - bg) <= BPP_TOL, (i, bw, bg)
+        dpb = dict(ctx_o)
+    assert strict >= 2, f"only {strict} of 3 frames were free of rounding ties"
