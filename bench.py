@@ -78,7 +78,7 @@ def conv_variant(n, cout, ho, wo, k, stride):
     mt = 2 if cout > 32 else 1
     nt = 2 if (stride == 2 and k != 1) else 4
     cblocks, tx = (cout + 32 * mt - 1) // (32 * mt), (wo + 31) // 32
-    while nt > 1 and ((ho + 4 * nt - 1) // (4 * nt)) * tx * cblocks * n < 512:
+    while nt > 1 and ((ho + 4 * nt - 1) // (4 * nt)) * tx * cblocks * n < 480:
         nt //= 2
     if mt == 2 and nt == 1 and ((ho + 3) // 4) * tx * cblocks * n < 384:
         mt = 1   # half-block variant: 32-channel workgroups on 64-wide packed weights

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const int e1 = e0 + a.src[1].channels;
   const int e2 = e1 + a.src[2].channels;
   const int cin = a.cin;
+  const bool single_src = a.n_src == 1;
   const bool in_act = a.in_act != 0;
   const float in_slope = a.in_slope;
 
@@ -192,16 +193,22 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       // plane of channel ci over the concatenated sources, as mask arithmetic (select chains on
       // these scalars get turned into a private-memory lookup table by the compiler); the
       // telescoping sums work because g2 implies g1 implies g0
-      const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
-      const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
-      const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
-      const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0), b1 = reinterpret_cast<unsigned long long>(sp1);
-      const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
-      const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
-      const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
-      const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
       const bool have = ci < cin;
-      const unsigned long long pl = have ? base + 4ull * (unsigned long long)((long long)(ci - first) * cs) : b0;
+      const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
+      unsigned long long pl;
+      if (single_src) {   // workgroup-uniform: the common case costs one multiply-add per channel
+        pl = have ? b0 + 4ull * (unsigned long long)((long long)ci * cs0) : b0;
+      } else {
+        const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
+        const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
+        const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
+        const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
+        const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
+        const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
+        const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
+        const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
+        pl = have ? base + 4ull * (unsigned long long)((long long)(ci - first) * cs) : b0;
+      }
       // wave-uniform buffer descriptor (made provably so for the compiler): base = plane,
       // size = H*W*4 bytes, or 0 past the last channel so that every load returns 0
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pl);
@@ -492,7 +499,7 @@ inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
   const long long tx = (a.wo + 31) / 32;
   for (int nt = max_nt; nt > 1; nt >>= 1) {
     const long long blocks = (long long)((a.ho + 4 * nt - 1) / (4 * nt)) * tx * cblocks * batch;
-    if (blocks >= 512) return nt;
+    if (blocks >= 480) return nt;   // (within a few percent of two workgroups per CU counts)
   }
   return 1;
 }
