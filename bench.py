@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--gop", type=int, default=12)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
-    ap.add_argument("--cpu-scale", type=int, default=3, help="CPU sample is the frame downscaled by this factor per side")
+    ap.add_argument("--cpu-scale", type=int, default=2, help="CPU sample is the frame downscaled by this factor per side")
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
                          "not the headline configuration")
@@ -174,25 +174,36 @@ def cpu_baseline(sd, args, threads):
     EO._EntropyModelBase.compress = compress
     EO._EntropyModelBase.decompress = decompress
 
+    def sample(scale, n_timed):
+        h, w = args.height // scale, args.width // scale
+        frames = [pad_to_multiple(f, 64) for f in synthetic_gop(1 + 1 + n_timed, h, w, seed=0)]
+        dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+        times = []
+        with torch.no_grad():
+            for x in frames[1:]:
+                t0 = time.perf_counter()
+                e = O.encode_inter(sd, ent, x, dpb)
+                rec, info = O.decode_inter(sd, ent, e["strings"], e["shape"], dpb)
+                rec = rec.clamp(0, 1)
+                times.append(time.perf_counter() - t0)
+                dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+                       "y_mv_ref": info["y_mv_ref"]}
+        t = sum(times[1:]) / len(times[1:])   # the first frame warms up the allocator / thread pool
+        area = (frames[0].shape[2] * frames[0].shape[3]) / float(pad64(args.height) * pad64(args.width))
+        return (1.0 / t) * area, t, tuple(frames[0].shape[2:]), len(times) - 1
+
     sc = max(1, args.cpu_scale)
-    h, w = args.height // sc, args.width // sc
-    frames = [pad_to_multiple(f, 64) for f in synthetic_gop(3, h, w, seed=0)]
-    dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
-    times = []
-    with torch.no_grad():
-        for x in frames[1:]:
-            t0 = time.perf_counter()
-            e = O.encode_inter(sd, ent, x, dpb)
-            rec, info = O.decode_inter(sd, ent, e["strings"], e["shape"], dpb)
-            rec = rec.clamp(0, 1)
-            times.append(time.perf_counter() - t0)
-            dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"], "y_mv_ref": info["y_mv_ref"]}
-    t = times[-1]  # first frame warms up the allocator / thread pool
-    area = (frames[0].shape[2] * frames[0].shape[3]) / float(pad64(args.height) * pad64(args.width))
-    fps_full = (1.0 / t) * area
-    return {"value": fps_full, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle encode_inter+decode_inter of 1 P frame at {frames[0].shape[2]}x{frames[0].shape[3]} "
-                      f"({t:.2f} s, after 1 warm-up frame), scaled by area to 1088x1920; fp32, {threads} threads"}
+    fps_full, t, shape, n = sample(sc, 2)
+    out = {"value": fps_full, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"oracle encode_inter+decode_inter of {n} P frames at {shape[0]}x{shape[1]} "
+                     f"({t:.2f} s each, after 1 warm-up frame), scaled by area to 1088x1920; fp32, {threads} threads"}
+    # the reference's own evaluation script pins one thread (dmc/test.py:27): smaller sample, same scaling
+    torch.set_num_threads(1)
+    fps1, t1, shape1, n1 = sample(2 * sc, 1)
+    torch.set_num_threads(threads)
+    out["single_thread"] = {"value": fps1, "cores": 1,
+                            "sample": f"{n1} P frame at {shape1[0]}x{shape1[1]} ({t1:.2f} s), scaled by area"}
+    return out
 
 
 def pad64(v):
