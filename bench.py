@@ -335,7 +335,7 @@ def main():
             "bpp": bpp, "psnr_db": sum(psnrs) / len(psnrs),
             "roofline": roof,
         }
-        if args.cpu_baseline:
+        if args.cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             cb = cpu_baseline(sd, args, threads)
             out["cpu_baseline"] = cb
