@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
                          "not the headline configuration")
-    ap.add_argument("--gops-in-flight", type=int, default=2,
+    ap.add_argument("--gops-in-flight", type=int, default=3,
                     help="independent GOPs coded concurrently per GPU (one host thread + HIP stream each); "
                          "a step codes this many GOPs per GPU")
     return ap.parse_args()
