@@ -16,3 +16,6 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fet
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --steps 1 --warmup 0 --gop 3 > $O/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_sq -o sq -- python3 tools/conv_bench.py --shapes main,c128_64 --iters 5 > $O/pmc_sq.log 2>&1
 find $O -name '*.csv' | xargs ls -la
+# MFMA pipe occupancy of the dominant conv shapes: busy cycles of the matrix pipe over all SIMDs
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o mfma -- python3 tools/conv_bench.py --shapes main,main,c128_64,k7_32_64 --iters 5 > $O/pmc_mfma.log 2>&1
+find $O/pmc_mfma -name '*.csv' | xargs ls -la
