@@ -22,6 +22,8 @@
 // Fused around the MFMA loop: channel concat of up to 4 sources and LeakyReLU on
 // the input while staging; bias, LeakyReLU/ReLU, (scaled) residual adds and the
 // PixelShuffle(2) scatter in the epilogue.
+#include <atomic>
+
 #include "dvc_common.h"
 
 namespace {
@@ -475,15 +477,20 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 template <int KS, int S, int MT, int NT, bool HALF = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
   using G = Geo<KS, S, MT, NT, HALF>;
-  static bool attr_set = false;   // LDS above the 64 KiB default needs the opt-in once per kernel
-  if (!attr_set) {
+  // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
+  // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
+  static std::atomic<unsigned long long> attr_done{0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
+  const unsigned long long device_bit = 1ull << device;
+  if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
       return DVC_EHIP;
     }
-    attr_set = true;
+    attr_done.fetch_or(device_bit, std::memory_order_release);
   }
   ConvArgs b = a;
   const int tiles_y = (a.ho + G::TH - 1) / G::TH;

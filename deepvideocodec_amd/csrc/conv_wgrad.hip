@@ -19,6 +19,8 @@
 // loads: padding and channels past the end arrive as zeros) while the previous tile is being
 // multiplied, then into LDS laid out [channel][pixel] with an odd channel stride, so that the
 // MFMA operands -- 32 lanes = 32 channels at one pixel -- are conflict-free LDS reads.
+#include <atomic>
+
 #include "dvc_common.h"
 
 namespace {
@@ -289,15 +291,20 @@ int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Pl
 template <int KS, int S, int MT, int CT>
 int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
   using G = WGeo<KS, S, MT, CT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
+  // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
+  static std::atomic<unsigned long long> attr_done{0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
+  const unsigned long long device_bit = 1ull << device;
+  if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, S, MT, CT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(wgrad %d,%d): %s", KS, S, hipGetErrorString(e));
       return DVC_EHIP;
     }
-    attr_set = true;
+    attr_done.fetch_or(device_bit, std::memory_order_release);
   }
   dim3 grid(p.nsplit, p.blocks, KS == 7 ? 7 : 1);
   hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, MT, CT>), grid, dim3(512), G::LDS_BYTES, st, a);
