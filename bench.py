@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0           # HBM3E peak (roof of the --precision bf16 option)
 
 
 def parse():
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--gop", type=int, default=12)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-scale", type=int, default=2, help="CPU sample is the frame downscaled by this factor per side")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
+                    help="bf16: reduced-precision convolutions (not the parity path; reported with its deviation "
+                         "from the fp32 path)")
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
                          "not the headline configuration")
@@ -231,6 +235,7 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
     net.update(force=True)
+    net.set_precision(args.precision)
 
     def clamp(x):
         return ops.clamp(x, 0.0, 1.0)
@@ -321,11 +326,17 @@ def main():
                                       "frac": all_flops / all_time / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                       "conv_ms_per_frame": all_time / 2 * 1e3,
                                       "conv_gflop_per_frame": all_flops / 2 / 1e9}}
+        if args.precision != "fp32":
+            # with bf16 operands the same launches sit under the HBM roof (fp32 activations in memory)
+            roof.update({"bound": "hbm", "kernel": kname + " (bf16 operands)", "achieved": nb / tm / 1e9,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / tm / 1e9 / PEAK_HBM_GBS,
+                         "mfma_tflops": fl / tm / 1e12, "traffic": None})
+            roof["all_conv_variants"].pop("frac")
         out = {
             "metric": "encode frames/sec + bpp@PSNR, 1080p GOP=12, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"DMC {args.height}x{args.width} (padded {pad64(args.height)}x{pad64(args.width)}) "
                                    f"GOP={args.gop} " + ("encode_inter_with_recon (encoder-side reuse)" if args.reuse
                                                          else "encode_inter+decode_inter") + " per P frame, batch=1 per GPU, "
@@ -335,6 +346,21 @@ def main():
             "bpp": bpp, "psnr_db": sum(psnrs) / len(psnrs),
             "roofline": roof,
         }
+        if args.precision != "fp32":
+            # deviation of the reduced-precision mode from the fp32 path on the first frames of a GOP
+            def quality(prec):
+                net.set_precision(prec)
+                b, recs = codec_gop(net, last[:4], clamp)
+                ps = []
+                for x, r in zip(last[1:4], recs):
+                    sse = ops.sq_err_sum(crop_to(x, (args.height, args.width)).contiguous(),
+                                         crop_to(r, (args.height, args.width)).contiguous()).item()
+                    ps.append(-10 * math.log10(sse / (3 * n_pix)))
+                return b * 8 / (n_pix * 3), sum(ps) / len(ps)
+            bpp32, psnr32 = quality("fp32")
+            bpp16, psnr16 = quality(args.precision)
+            out["vs_fp32"] = {"frames": 3, "bpp_fp32": bpp32, "bpp": bpp16, "d_bpp": bpp16 - bpp32,
+                              "psnr_fp32_db": psnr32, "psnr_db": psnr16, "d_psnr_db": psnr16 - psnr32}
         if args.cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             cb = cpu_baseline(sd, args, threads)

@@ -29,6 +29,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvArgs {
   DvcSrc src[DVC_MAX_SRC];
@@ -58,6 +59,29 @@ constexpr int cout_block_of(int cout) { return cout > 32 ? 64 : 32; }
 // pieces (one global_load_lds wave-instruction moves 64 lanes x 16 B)
 constexpr int slab_floats(int ks, int s, int cb) { return (chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
 
+// bf16 compute mode: K step of the MFMA is 16 input channels, held by a lane as 8 consecutive
+// channels (one "octet", 16 bytes).  A slab is [tap][octet 0/1][co][8 channels] in bf16, its size
+// given here in 4-byte units like the fp32 slabs (padded to whole 1 KiB pieces).
+constexpr int BF_CK = 16;
+constexpr int slab_floats_bf16(int ks, int cb) { return (ks * ks * 2 * cb * 4 + 255) / 256 * 256; }
+
+__global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* w, __bf16* packed, int cout, int cin, int ks,
+                                                               int cb, int slab_elems, int nchunks, long long total) {
+  const int taps = ks * ks;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i % slab_elems);
+    const long long t = i / slab_elems;
+    const int chunk = (int)(t % nchunks), blk = (int)(t / nchunks);
+    const int e8 = e & 7, u = e >> 3;
+    const int col = u % cb, q = u / cb;
+    const int o = q & 1, tap = q >> 1;
+    const int ci = chunk * BF_CK + o * 8 + e8, co = blk * cb + col;
+    float v = 0.f;
+    if (tap < taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
+    packed[i] = (__bf16)v;
+  }
+}
+
 // OIHW -> [cout block][chunk][row = (ci - c0) * taps + tap][co - cb0], zero filled past Cin / Cout.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* packed, int cout, int cin, int ks,
                                                           int ck, int cb, int slab, int nchunks, long long total) {
@@ -80,10 +104,12 @@ constexpr int min_waves_per_simd() { return 2; }
 
 // HALF: a 32-channel workgroup (MT = 1) working on one half of a 64-channel packed weight block,
 // used to double the number of workgroups of small launches whose weights are packed 64 wide.
-template <int KS, int S, int MT, int NT, bool HALF = false>
+// BF: bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) instead of exact fp32.
+template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
 struct Geo {
   static_assert(!HALF || MT == 1, "half blocks are 32 channels");
-  static constexpr int CK = chunk_of(KS, S);
+  static_assert(!BF || KS != 7, "bf16 mode covers the 1x1 and 3x3 layers");
+  static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
   static constexpr int IH = (TH - 1) * SL + KS;
@@ -92,16 +118,19 @@ struct Geo {
   static constexpr int TAPS = KS * KS;
   static constexpr int KCH = CK * TAPS;          // k values per chunk
   static constexpr int CBP = HALF ? 64 : CB;     // output channels per packed weight row
-  static constexpr int SLAB = slab_floats(KS, S, CBP);
-  static constexpr int IN_BUF = (CK * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
+  static constexpr int SLAB = BF ? slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
+  // fp32: [channel][element]; bf16: [octet][element][8 channels] = 8 * CHS 4-byte units
+  static constexpr int IN_BUF = ((BF ? 8 : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
-  static constexpr int LDS_BYTES = (2 * IN_BUF + 2 * SLAB) * 4;
+  static constexpr int STAGE_BYTES = (2 * IN_BUF + 2 * SLAB) * 4;
+  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4;   // four wave-private 32 x 36 transposition tiles
+  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int KS, int S, int MT, int NT, bool HALF = false>
+template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
-  using G = Geo<KS, S, MT, NT, HALF>;
+  using G = Geo<KS, S, MT, NT, HALF, BF>;
   constexpr int CBP = G::CBP;
   constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW;
   constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
@@ -232,11 +261,27 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 #pragma unroll
         for (int j = 0; j < IN_PT; ++j) rin[c][j] = dvc::leaky(rin[c][j], in_slope);
     }
+    if constexpr (BF) {
+      // element i of the tile gets its 16 channels as two 16-byte octets: [octet][i][8 x bf16]
+      bf16x8* const d8 = reinterpret_cast<bf16x8*>(in_s + buf * IN_BUF) + tid;
 #pragma unroll
-    for (int c = 0; c < CK; ++c) {
+      for (int j = 0; j < IN_PT; ++j)
+        if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) {
 #pragma unroll
-      for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
-        if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
+          for (int o = 0; o < 2; ++o) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)rin[8 * o + e][j];
+            d8[o * CHS + 256 * j] = v;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+#pragma unroll
+        for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
+          if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
+      }
     }
   };
 
@@ -250,6 +295,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 
   const int b_lane = half * CHS + (wave * NT * SL) * IW + l32 * SL;
   const int a_lane = (half * TAPS) * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
+  // bf16 mode, in 16-byte units: A [tap][octet][co], B [octet][element]
+  const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
+  const int b_lane8 = half * CHS + (wave * NT * SL) * IW + l32 * SL;
 
   // ---- prologue: chunk 0 into buffer 0
   dma_weights(0, 0);
@@ -264,32 +312,55 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       dma_weights(k + 1, cur ^ 1);
       prefetch_input((k + 1) * CK);
     }
-    const float* bbase = in_s + cur * IN_BUF + b_lane;
-    const float* abase = w_s + cur * SLAB + a_lane;
-    constexpr int T = (CK / 2) * TAPS;
-    float av[2][MT], bv[2][NT];
-    auto fetch = [&](int t, int slot) {
-      const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
+    if constexpr (BF) {
+      const bf16x8* bbase = reinterpret_cast<const bf16x8*>(in_s + cur * IN_BUF) + b_lane8;
+      const bf16x8* abase = reinterpret_cast<const bf16x8*>(w_s + cur * SLAB) + a_lane8;
+      bf16x8 av[2][MT], bv[2][NT];
+      auto fetch = [&](int tap, int slot) {
+        const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CBP + mt * 32];
+        for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[tap * 2 * CBP + mt * 32];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
-    };
-    fetch(0, 0);
+        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[(nt * SL + ky) * IW + kx];
+      };
+      fetch(0, 0);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
-#ifndef DVC_NO_SCHED_PIN
-      __builtin_amdgcn_sched_barrier(0);          // keep those LDS reads ahead of this tap's MFMAs
-#endif
+      for (int t = 0; t < TAPS; ++t) {
+        if (t + 1 < TAPS) fetch(t + 1, (t + 1) & 1);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
-#ifndef DVC_NO_SCHED_PIN
-      __builtin_amdgcn_sched_barrier(0);
-#endif
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else {
+      const float* bbase = in_s + cur * IN_BUF + b_lane;
+      const float* abase = w_s + cur * SLAB + a_lane;
+      constexpr int T = (CK / 2) * TAPS;
+      float av[2][MT], bv[2][NT];
+      auto fetch = [&](int t, int slot) {
+        const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
+  #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CBP + mt * 32];
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
+      };
+      fetch(0, 0);
+  #pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
+  #ifndef DVC_NO_SCHED_PIN
+        __builtin_amdgcn_sched_barrier(0);          // keep those LDS reads ahead of this tap's MFMAs
+  #endif
+  #pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+  #ifndef DVC_NO_SCHED_PIN
+        __builtin_amdgcn_sched_barrier(0);
+  #endif
+      }
     }
     if (k + 1 < nchunks) commit_input(cur ^ 1);   // buffer cur^1 was last read before the previous barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
@@ -474,9 +545,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   }
 }
 
-template <int KS, int S, int MT, int NT, bool HALF = false>
+template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
-  using G = Geo<KS, S, MT, NT, HALF>;
+  using G = Geo<KS, S, MT, NT, HALF, BF>;
   // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
   // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
   static std::atomic<unsigned long long> attr_done{0};
@@ -484,7 +555,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
   const unsigned long long device_bit = 1ull << device;
   if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
@@ -496,7 +567,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   const int tiles_y = (a.ho + G::TH - 1) / G::TH;
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
   dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF>), grid, dim3(256), G::LDS_BYTES, st, b);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>), grid, dim3(256), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
 }
 
@@ -511,23 +582,23 @@ inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
   return 1;
 }
 
-template <int KS, int S>
+template <int KS, int S, bool BF = false>
 int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   const int mt = a.cout > 32 ? 2 : 1;
   // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
   // workgroups per CU, so those stop at 8 rows
   const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : 4);
   if (mt == 2) {
-    if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 2, 4>(a, batch, st); }
-    if (nt == 2) return launch<KS, S, 2, 2>(a, batch, st);
+    if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 2, 4, false, BF>(a, batch, st); }
+    if (nt == 2) return launch<KS, S, 2, 2, false, BF>(a, batch, st);
     // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
     const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
-    if (blocks < 384) return launch<KS, S, 1, 1, true>(a, batch, st);
-    return launch<KS, S, 2, 1>(a, batch, st);
+    if (blocks < 384) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
+    return launch<KS, S, 2, 1, false, BF>(a, batch, st);
   }
-  if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4>(a, batch, st); }
-  if (nt == 2) return launch<KS, S, 1, 2>(a, batch, st);
-  return launch<KS, S, 1, 1>(a, batch, st);
+  if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4, false, BF>(a, batch, st); }
+  if (nt == 2) return launch<KS, S, 1, 2, false, BF>(a, batch, st);
+  return launch<KS, S, 1, 1, false, BF>(a, batch, st);
 }
 
 int check_geometry(int cout, int cin, int ks, int stride, const char* who) {
@@ -558,6 +629,30 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
   hipLaunchKernelGGL(pack_weight_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
                      packed, cout, cin, ksize, ck, cb, slab, nchunks, total);
   return dvc::check_launch("pack_weight_kernel");
+}
+
+extern "C" int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride) {
+  if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_packed_weight_floats")) return DVC_EINVAL;
+  if (ksize == 7) {
+    dvc::set_error("dvc_conv2d_bf16_packed_weight_floats: the bf16 mode covers ksize 1 and 3");
+    return DVC_EINVAL;
+  }
+  const int cb = cout_block_of(cout);
+  return (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK) * slab_floats_bf16(ksize, cb);
+}
+
+extern "C" int dvc_conv2d_bf16_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize,
+                                           int32_t stride, float* packed, void* stream) {
+  if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_pack_weight")) return rc;
+  DVC_REQUIRE(ksize != 7, "dvc_conv2d_bf16_pack_weight: the bf16 mode covers ksize 1 and 3");
+  DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_bf16_pack_weight: null pointer");
+  DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_bf16_pack_weight: packed buffer must be 16-byte aligned");
+  const int cb = cout_block_of(cout);
+  const int slab_elems = 2 * slab_floats_bf16(ksize, cb), nchunks = (cin + BF_CK - 1) / BF_CK;
+  const long long total = (long long)((cout + cb - 1) / cb) * nchunks * slab_elems;
+  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     weight, reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, slab_elems, nchunks, total);
+  return dvc::check_launch("pack_weight_bf16_kernel");
 }
 
 extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
@@ -631,6 +726,12 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   a.in_act = p->in_act ? 1 : 0;
   a.out_act = p->out_act ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->compute_bf16) {
+    DVC_REQUIRE(p->ksize != 7, "dvc_conv2d: the bf16 mode covers ksize 1 and 3");
+    if (p->ksize == 3)
+      return p->stride == 1 ? dispatch_tile<3, 1, true>(a, p->batch, st) : dispatch_tile<3, 2, true>(a, p->batch, st);
+    return p->stride == 1 ? dispatch_tile<1, 1, true>(a, p->batch, st) : dispatch_tile<1, 2, true>(a, p->batch, st);
+  }
   if (p->ksize == 3) return p->stride == 1 ? dispatch_tile<3, 1>(a, p->batch, st) : dispatch_tile<3, 2>(a, p->batch, st);
   if (p->ksize == 1) return p->stride == 1 ? dispatch_tile<1, 1>(a, p->batch, st) : dispatch_tile<1, 2>(a, p->batch, st);
   return dispatch_tile<7, 1>(a, p->batch, st);

@@ -34,18 +34,24 @@ class Conv2d(nn.Module):
         nn.init.xavier_normal_(self.weight, math.sqrt(2))
         nn.init.constant_(self.bias, 0.01)
 
-        self._packed = None       # kernel-layout image of `weight`
-        self._packed_key = None   # (storage address, version counter) it was built from
+        self._packed = {}         # compute mode -> (key, kernel-layout image of `weight`)
+        # inference-only option: operands rounded to bf16, fp32 accumulation (1x1 / 3x3 kernels; the
+        # 7x7 motion-estimation layers always stay exact fp32).  See DMC.set_precision().
+        self.compute_bf16 = False
 
-    def packed_weight(self) -> Tensor:
-        """The slab-layout copy of the weight the kernel reads, rebuilt when the parameter is
-        modified in place (optimizer step, load_state_dict) or moved (`.to(device)`)."""
+    def _bf16(self) -> bool:
+        return self.compute_bf16 and self.kernel_size != 7
+
+    def packed_weight(self, bf16: bool = False) -> Tensor:
+        """The slab-layout copy of the weight the kernel reads (one per compute mode), rebuilt when
+        the parameter is modified in place (optimizer step, load_state_dict) or moved (`.to(device)`)."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
-        if self._packed is None or self._packed_key != key:
-            self._packed = ops.pack_conv_weight(w.detach().contiguous(), self.stride)
-            self._packed_key = key
-        return self._packed
+        hit = self._packed.get(bf16)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_conv_weight(w.detach().contiguous(), self.stride, bf16=bf16))
+            self._packed[bf16] = hit
+        return hit[1]
 
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
                 pixel_shuffle=False, out=None) -> Tensor:
@@ -58,7 +64,8 @@ class Conv2d(nn.Module):
                             pixel_shuffle=pixel_shuffle, packed=self.packed_weight())
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
-                          pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight())
+                          pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._bf16()),
+                          bf16=self._bf16())
 
 
 def conv1x1(in_ch, out_ch, stride=1):

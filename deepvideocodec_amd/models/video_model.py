@@ -491,9 +491,21 @@ class DMC(nn.Module):
         for them; call once before driving the model from several host threads / streams."""
         for m in self.modules():
             if isinstance(m, Conv2d):
-                m.packed_weight()
+                m.packed_weight(m._bf16())
         if next(self.parameters()).is_cuda:
             torch.cuda.synchronize()
+        return self
+
+    def set_precision(self, precision: str = "fp32"):
+        """"fp32" (default): exact fp32 convolutions, the parity path.  "bf16": the 1x1 / 3x3
+        convolutions round their operands to bf16 and accumulate in fp32 (3-4x faster, results differ
+        from the fp32 path; encoder and decoder must use the same setting).  Inference only: under
+        autograd the convolutions always run in fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"unknown precision {precision!r}")
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.compute_bf16 = precision == "bf16"
         return self
 
     def aux_loss(self):

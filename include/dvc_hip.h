@@ -86,6 +86,10 @@ typedef struct DvcConv2d {
   const float* res_scale;          /* NULL or [batch][out channels after shuffle] */
   const float* residual2;          /* NULL or a second tensor in output layout (needs residual) */
   int64_t res2_batch_stride, res2_chan_stride;
+  int32_t compute_bf16;            /* 0: exact fp32 MFMA (weight_packed from dvc_conv2d_pack_weight);
+                                      1: operands rounded to bf16, fp32 accumulate (weight_packed from
+                                      dvc_conv2d_bf16_pack_weight; ksize 1 or 3 only) */
+  int32_t _pad;
 } DvcConv2d;
 
 int dvc_conv2d(const DvcConv2d* p, void* stream);
@@ -98,6 +102,12 @@ int dvc_conv2d(const DvcConv2d* p, void* stream);
 int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
+
+/* The same for the bf16 compute mode (a reduced-precision option, not the parity path): slabs are
+ * [tap][8-channel octet 0/1][co][8 x bf16] per 16 input channels; the size is returned in 4-byte units. */
+int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
+int dvc_conv2d_bf16_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
+                                int32_t stride, float* packed, void* stream);
 
 /* Backward bilinear warp, border clamp, flow in pixels (ch0 = x, ch1 = y):
  * layers.py:175-198 (`torch_warp` = grid_sample(bilinear, border, align_corners=True)). */

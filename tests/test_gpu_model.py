@@ -301,3 +301,42 @@ def test_config0_256x256_gop4_random_frames_vs_oracle(gpu_net, seeded_sd, oracle
             assert abs(bw - bg) <= BPP_TOL, (i, bw, bg)
         dpb = dict(ctx_o)
     assert strict >= 2, f"only {strict} of 3 frames were free of rounding ties"
+
+
+def test_bf16_precision_option(seeded_sd):
+    """The reduced-precision option: encoder and decoder stay consistent (the stream decodes to the
+    encoder's reconstruction), results stay close to the fp32 path, and switching back restores it."""
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda().eval()
+    net.update(force=True)
+    frames = [f.cuda() for f in synthetic_gop(3, 128, 192, seed=23)]
+    n_pix = 128 * 192
+
+    def run():
+        dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+        nbytes, recs = 0, []
+        for x in frames[1:]:
+            enc, rec_e, _ = net.encode_inter_with_recon(x, dpb)
+            rec, info = net.decode_inter(enc["strings"], enc["shape"], dpb)
+            assert torch.equal(rec, rec_e)                     # decoder == encoder-side reconstruction
+            nbytes += sum(len(s[0]) for v in enc["strings"].values() for s in v)
+            recs.append(rec)
+            dpb = {"x_ref": rec.clamp(0, 1), "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+                   "y_mv_ref": info["y_mv_ref"]}
+        return nbytes * 8 / (2 * n_pix), [psnr(x.cpu(), r.cpu()) for x, r in zip(frames[1:], recs)], recs
+
+    bpp32, psnr32, rec32 = run()
+    net.set_precision("bf16")
+    assert net.contextual_encoder.conv1._bf16() and not net.optic_flow.moduleBasic[0].conv1._bf16()
+    bpp16, psnr16, rec16 = run()
+    assert not torch.equal(rec16[0], rec32[0])                 # it really is a different arithmetic
+    assert abs(bpp16 - bpp32) <= 0.03 * bpp32, (bpp16, bpp32)
+    assert all(abs(a - b) <= 0.1 for a, b in zip(psnr16, psnr32)), (psnr16, psnr32)
+    net.set_precision("fp32")
+    bpp_again, _, rec_again = run()
+    assert bpp_again == bpp32 and torch.equal(rec_again[1], rec32[1])
+    with pytest.raises(ValueError):
+        net.set_precision("fp8")

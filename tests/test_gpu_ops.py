@@ -347,3 +347,43 @@ def test_bits_and_sse_reductions():
     assert ((got - want).abs() / want).max().item() < 2e-6
     # deterministic: two runs are bit-identical
     assert torch.equal(ops.likelihood_bits(dev(lik)), ops.likelihood_bits(dev(lik)))
+
+
+BF16_CASES = [
+    # k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle
+    (3, 1, (64,), 64, 36, 52, 1, None, None, False),
+    (3, 1, (16, 8), 40, 17, 23, 2, 0.1, 0.01, False),
+    (3, 1, (5, 7, 9, 11), 96, 21, 19, 1, None, 0.0, False),
+    (3, 2, (67,), 64, 32, 48, 1, None, 0.1, False),
+    (1, 1, (64,), 32, 33, 47, 1, None, None, False),
+    (1, 2, (12,), 64, 34, 50, 2, None, None, False),
+    (3, 1, (24,), 32, 10, 14, 2, None, 0.01, True),
+    (3, 1, (288,), 288, 17, 30, 1, None, 0.2, False),
+    (3, 1, (64,), 64, 272, 480, 1, 0.01, 0.01, False),
+]
+
+
+@pytest.mark.parametrize("k,stride,cins,cout,H,W,batch,in_slope,out_slope,shuffle", BF16_CASES)
+def test_conv2d_bf16_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle):
+    """The reduced-precision mode: operands rounded to bf16 (after the input activation), products and
+    sums in fp32 -- so it must agree with an fp32 convolution of the rounded operands to fp32 noise."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(k * 31 + cout + W)
+    parts = [torch.randn(batch, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(batch, cout // 4 if shuffle else cout, *( (2 * ((H + 2 * (k // 2) - k) // stride + 1), 2 * ((W + 2 * (k // 2) - k) // stride + 1)) if shuffle
+                      else ((H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1)), generator=g)
+    x = torch.cat(parts, 1)
+    if in_slope is not None:
+        x = F.leaky_relu(x, in_slope)
+    want = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, stride=stride, padding=k // 2)
+    if out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    want = (F.pixel_shuffle(want, 2) if shuffle else want) + res
+    got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), stride=stride, in_slope=in_slope, out_slope=out_slope,
+                     pixel_shuffle=shuffle, residual=dev(res), bf16=True)
+    close(got, want, rel=2e-5)
+    with pytest.raises(Exception):
+        ops.conv2d(dev(torch.randn(1, 8, 16, 16)), dev(torch.randn(8, 8, 7, 7)), None, bf16=True)

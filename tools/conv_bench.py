@@ -47,6 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
+    ap.add_argument("--bf16", type=int, default=0, help="1: the reduced-precision bf16 compute mode (k 1/3 only)")
     ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
     args = ap.parse_args()
     names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
@@ -63,14 +64,15 @@ def main():
         x = torch.randn(1, cin, h, w, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
-        packed = ops.pack_conv_weight(wt, s)
-        out = ops.conv2d(x, wt, b, stride=s, packed=packed)
+        bf = bool(args.bf16) and k != 7
+        packed = ops.pack_conv_weight(wt, s, bf16=bf)
+        out = ops.conv2d(x, wt, b, stride=s, packed=packed, bf16=bf)
         for _ in range(2):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, bf16=bf)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, bf16=bf)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
