@@ -42,8 +42,8 @@ def parse():
     ap.add_argument("--gop", type=int, default=12)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-scale", type=int, default=2, help="CPU sample is the frame downscaled by this factor per side")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
-                    help="bf16: reduced-precision convolutions (not the parity path; reported with its deviation "
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16", "bf16x2"),
+                    help="bf16 / bf16x2: reduced-precision convolutions (not the parity path; reported with its deviation "
                          "from the fp32 path)")
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
@@ -328,7 +328,7 @@ def main():
                                       "conv_gflop_per_frame": all_flops / 2 / 1e9}}
         if args.precision != "fp32":
             # with bf16 operands the same launches sit under the HBM roof (fp32 activations in memory)
-            roof.update({"bound": "hbm", "kernel": kname + " (bf16 operands)", "achieved": nb / tm / 1e9,
+            roof.update({"bound": "hbm", "kernel": kname + f" ({args.precision} operands)", "achieved": nb / tm / 1e9,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb / tm / 1e9 / PEAK_HBM_GBS,
                          "mfma_tflops": fl / tm / 1e12, "traffic": None})
             roof["all_conv_variants"].pop("frac")
@@ -336,7 +336,7 @@ def main():
             "metric": "encode frames/sec + bpp@PSNR, 1080p GOP=12, 1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else args.precision + " operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"DMC {args.height}x{args.width} (padded {pad64(args.height)}x{pad64(args.width)}) "
                                    f"GOP={args.gop} " + ("encode_inter_with_recon (encoder-side reuse)" if args.reuse
                                                          else "encode_inter+decode_inter") + " per P frame, batch=1 per GPU, "

@@ -60,8 +60,8 @@ SIGNATURES = {
     "dvc_conv2d": (C.c_int, [C.POINTER(DvcConv2d), _P]),
     "dvc_conv2d_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "dvc_conv2d_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
-    "dvc_conv2d_bf16_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
-    "dvc_conv2d_bf16_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
+    "dvc_conv2d_bf16_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "dvc_conv2d_bf16_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
     "dvc_flow_warp": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_avg_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
     "dvc_max_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),

@@ -66,19 +66,23 @@ constexpr int BF_CK = 16;
 constexpr int slab_floats_bf16(int ks, int cb) { return (ks * ks * 2 * cb * 4 + 255) / 256 * 256; }
 
 __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* w, __bf16* packed, int cout, int cin, int ks,
-                                                               int cb, int slab_elems, int nchunks, long long total) {
+                                                               int cb, int part_elems, int parts, int nchunks,
+                                                               long long total) {
   const int taps = ks * ks;
+  const int slab_elems = part_elems * parts;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int e = (int)(i % slab_elems);
     const long long t = i / slab_elems;
     const int chunk = (int)(t % nchunks), blk = (int)(t / nchunks);
-    const int e8 = e & 7, u = e >> 3;
+    const int part = e / part_elems, ep = e - part * part_elems;
+    const int e8 = ep & 7, u = ep >> 3;
     const int col = u % cb, q = u / cb;
     const int o = q & 1, tap = q >> 1;
     const int ci = chunk * BF_CK + o * 8 + e8, co = blk * cb + col;
     float v = 0.f;
     if (tap < taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
-    packed[i] = (__bf16)v;
+    const __bf16 hi = (__bf16)v;
+    packed[i] = part == 0 ? hi : (__bf16)(v - (float)hi);
   }
 }
 
@@ -104,11 +108,17 @@ constexpr int min_waves_per_simd() { return 2; }
 
 // HALF: a 32-channel workgroup (MT = 1) working on one half of a 64-channel packed weight block,
 // used to double the number of workgroups of small launches whose weights are packed 64 wide.
-// BF: bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) instead of exact fp32.
-template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
+// BF: 0 = exact fp32 MFMA.  1 = operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// 2 = every operand split into two bf16 parts, hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits), and
+// a product taken as hi*hi + hi*lo + lo*hi on the same MFMA: three bf16 MFMAs per 16 channels instead of
+// eight fp32 ones, relative error of a product <= ~2^-16.  With two parts the operand tiles are twice as
+// large and the LDS buffers are single (the next chunk is staged after the MFMA phase, not during it).
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 struct Geo {
   static_assert(!HALF || MT == 1, "half blocks are 32 channels");
-  static_assert(!BF || KS != 7, "bf16 mode covers the 1x1 and 3x3 layers");
+  static_assert(!BF || KS != 7, "the bf16 modes cover the 1x1 and 3x3 layers");
+  static constexpr int PARTS = BF ? BF : 1;
+  static constexpr int NBUF = BF == 2 ? 1 : 2;   // LDS buffers per operand
   static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
@@ -118,17 +128,17 @@ struct Geo {
   static constexpr int TAPS = KS * KS;
   static constexpr int KCH = CK * TAPS;          // k values per chunk
   static constexpr int CBP = HALF ? 64 : CB;     // output channels per packed weight row
-  static constexpr int SLAB = BF ? slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
+  static constexpr int SLAB = BF ? PARTS * slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
   // fp32: [channel][element]; bf16: [octet][element][8 channels] = 8 * CHS 4-byte units
-  static constexpr int IN_BUF = ((BF ? 8 : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
+  static constexpr int IN_BUF = ((BF ? 8 * PARTS : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
-  static constexpr int STAGE_BYTES = (2 * IN_BUF + 2 * SLAB) * 4;
+  static constexpr int STAGE_BYTES = NBUF * (IN_BUF + SLAB) * 4;
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4;   // four wave-private 32 x 36 transposition tiles
   static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
   using G = Geo<KS, S, MT, NT, HALF, BF>;
   constexpr int CBP = G::CBP;
@@ -136,8 +146,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const w_s = lds;                // [2][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
-  float* const in_s = lds + 2 * SLAB;    // [2][IN_BUF]
+  constexpr int NBUF = G::NBUF, PARTS = G::PARTS;
+  float* const w_s = lds;                   // [NBUF][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
+  float* const in_s = lds + NBUF * SLAB;    // [NBUF][IN_BUF]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
@@ -269,10 +280,14 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
         if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) {
 #pragma unroll
           for (int o = 0; o < 2; ++o) {
-            bf16x8 v;
+            bf16x8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (__bf16)rin[8 * o + e][j];
-            d8[o * CHS + 256 * j] = v;
+            for (int e = 0; e < 8; ++e) {
+              hi[e] = (__bf16)rin[8 * o + e][j];
+              if constexpr (PARTS == 2) lo[e] = (__bf16)(rin[8 * o + e][j] - (float)hi[e]);
+            }
+            d8[o * CHS + 256 * j] = hi;
+            if constexpr (PARTS == 2) d8[(2 + o) * CHS + 256 * j] = lo;   // [part][octet][element]
           }
         }
     } else {
@@ -307,31 +322,58 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   __syncthreads();
 
   for (int k = 0; k < nchunks; ++k) {
-    const int cur = k & 1;
+    const int cur = NBUF == 2 ? (k & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
     if (k + 1 < nchunks) {   // chunk k+1 in flight during the MFMA phase
-      dma_weights(k + 1, cur ^ 1);
+      if (NBUF == 2) dma_weights(k + 1, nxt);
       prefetch_input((k + 1) * CK);
     }
     if constexpr (BF) {
       const bf16x8* bbase = reinterpret_cast<const bf16x8*>(in_s + cur * IN_BUF) + b_lane8;
       const bf16x8* abase = reinterpret_cast<const bf16x8*>(w_s + cur * SLAB) + a_lane8;
-      bf16x8 av[2][MT], bv[2][NT];
-      auto fetch = [&](int tap, int slot) {
-        const int ky = tap / KS, kx = tap - ky * KS;
+      if constexpr (PARTS == 1) {
+        bf16x8 av[2][MT], bv[2][NT];
+        auto fetch = [&](int tap, int slot) {
+          const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[tap * 2 * CBP + mt * 32];
+          for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[tap * 2 * CBP + mt * 32];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[(nt * SL + ky) * IW + kx];
-      };
-      fetch(0, 0);
+          for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[(nt * SL + ky) * IW + kx];
+        };
+        fetch(0, 0);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        if (t + 1 < TAPS) fetch(t + 1, (t + 1) & 1);
+        for (int t = 0; t < TAPS; ++t) {
+          if (t + 1 < TAPS) fetch(t + 1, (t + 1) & 1);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+        }
+      } else {
+        // split operands: A parts [part][tap][octet][co], B parts [part][octet][element]; the small
+        // cross terms are accumulated before the leading one
+        constexpr int APART = TAPS * 2 * CBP, BPART = 2 * CHS;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int ky = t / KS, kx = t - ky * KS;
+          bf16x8 ah[MT], al[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = abase[t * 2 * CBP + mt * 32];
+            al[mt] = abase[APART + t * 2 * CBP + mt * 32];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 bh = bbase[(nt * SL + ky) * IW + kx];
+            const bf16x8 bl = bbase[BPART + (nt * SL + ky) * IW + kx];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+            }
+          }
+        }
       }
     } else {
       const float* bbase = in_s + cur * IN_BUF + b_lane;
@@ -362,7 +404,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   #endif
       }
     }
-    if (k + 1 < nchunks) commit_input(cur ^ 1);   // buffer cur^1 was last read before the previous barrier
+    if (NBUF == 1) {   // single buffers: everyone must be done reading before the next chunk lands
+      __syncthreads();
+      if (k + 1 < nchunks) dma_weights(k + 1, 0);
+    }
+    if (k + 1 < nchunks) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
     __syncthreads();
   }
@@ -545,7 +591,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   }
 }
 
-template <int KS, int S, int MT, int NT, bool HALF = false, bool BF = false>
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
   using G = Geo<KS, S, MT, NT, HALF, BF>;
   // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
@@ -582,7 +628,7 @@ inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
   return 1;
 }
 
-template <int KS, int S, bool BF = false>
+template <int KS, int S, int BF = 0>
 int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   const int mt = a.cout > 32 ? 2 : 1;
   // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
@@ -631,27 +677,28 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
   return dvc::check_launch("pack_weight_kernel");
 }
 
-extern "C" int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride) {
+extern "C" int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                                        int32_t parts) {
   if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_packed_weight_floats")) return DVC_EINVAL;
-  if (ksize == 7) {
-    dvc::set_error("dvc_conv2d_bf16_packed_weight_floats: the bf16 mode covers ksize 1 and 3");
+  if (ksize == 7 || parts < 1 || parts > 2) {
+    dvc::set_error("dvc_conv2d_bf16_packed_weight_floats: the bf16 modes cover ksize 1 and 3, parts 1 or 2");
     return DVC_EINVAL;
   }
   const int cb = cout_block_of(cout);
-  return (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK) * slab_floats_bf16(ksize, cb);
+  return (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK) * parts * slab_floats_bf16(ksize, cb);
 }
 
 extern "C" int dvc_conv2d_bf16_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize,
-                                           int32_t stride, float* packed, void* stream) {
+                                           int32_t stride, int32_t parts, float* packed, void* stream) {
   if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_pack_weight")) return rc;
-  DVC_REQUIRE(ksize != 7, "dvc_conv2d_bf16_pack_weight: the bf16 mode covers ksize 1 and 3");
+  DVC_REQUIRE(ksize != 7 && parts >= 1 && parts <= 2, "dvc_conv2d_bf16_pack_weight: the bf16 modes cover ksize 1 and 3, parts 1 or 2");
   DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_bf16_pack_weight: null pointer");
   DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_bf16_pack_weight: packed buffer must be 16-byte aligned");
   const int cb = cout_block_of(cout);
-  const int slab_elems = 2 * slab_floats_bf16(ksize, cb), nchunks = (cin + BF_CK - 1) / BF_CK;
-  const long long total = (long long)((cout + cb - 1) / cb) * nchunks * slab_elems;
+  const int part_elems = 2 * slab_floats_bf16(ksize, cb), nchunks = (cin + BF_CK - 1) / BF_CK;
+  const long long total = (long long)((cout + cb - 1) / cb) * nchunks * part_elems * parts;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     weight, reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, slab_elems, nchunks, total);
+                     weight, reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, part_elems, parts, nchunks, total);
   return dvc::check_launch("pack_weight_bf16_kernel");
 }
 
@@ -727,10 +774,16 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   a.out_act = p->out_act ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p->compute_bf16) {
-    DVC_REQUIRE(p->ksize != 7, "dvc_conv2d: the bf16 mode covers ksize 1 and 3");
+    DVC_REQUIRE(p->ksize != 7 && (p->compute_bf16 == 1 || p->compute_bf16 == 2),
+                "dvc_conv2d: the bf16 modes (1: rounded, 2: split) cover ksize 1 and 3");
+    if (p->compute_bf16 == 1) {
+      if (p->ksize == 3)
+        return p->stride == 1 ? dispatch_tile<3, 1, 1>(a, p->batch, st) : dispatch_tile<3, 2, 1>(a, p->batch, st);
+      return p->stride == 1 ? dispatch_tile<1, 1, 1>(a, p->batch, st) : dispatch_tile<1, 2, 1>(a, p->batch, st);
+    }
     if (p->ksize == 3)
-      return p->stride == 1 ? dispatch_tile<3, 1, true>(a, p->batch, st) : dispatch_tile<3, 2, true>(a, p->batch, st);
-    return p->stride == 1 ? dispatch_tile<1, 1, true>(a, p->batch, st) : dispatch_tile<1, 2, true>(a, p->batch, st);
+      return p->stride == 1 ? dispatch_tile<3, 1, 2>(a, p->batch, st) : dispatch_tile<3, 2, 2>(a, p->batch, st);
+    return p->stride == 1 ? dispatch_tile<1, 1, 2>(a, p->batch, st) : dispatch_tile<1, 2, 2>(a, p->batch, st);
   }
   if (p->ksize == 3) return p->stride == 1 ? dispatch_tile<3, 1>(a, p->batch, st) : dispatch_tile<3, 2>(a, p->batch, st);
   if (p->ksize == 1) return p->stride == 1 ? dispatch_tile<1, 1>(a, p->batch, st) : dispatch_tile<1, 2>(a, p->batch, st);

@@ -37,12 +37,12 @@ class Conv2d(nn.Module):
         self._packed = {}         # compute mode -> (key, kernel-layout image of `weight`)
         # inference-only option: operands rounded to bf16, fp32 accumulation (1x1 / 3x3 kernels; the
         # 7x7 motion-estimation layers always stay exact fp32).  See DMC.set_precision().
-        self.compute_bf16 = False
+        self.compute_bf16 = 0   # 0 exact fp32, 1 bf16-rounded operands, 2 split bf16 hi + lo operands
 
-    def _bf16(self) -> bool:
-        return self.compute_bf16 and self.kernel_size != 7
+    def _bf16(self) -> int:
+        return int(self.compute_bf16) if self.kernel_size != 7 else 0
 
-    def packed_weight(self, bf16: bool = False) -> Tensor:
+    def packed_weight(self, bf16: int = 0) -> Tensor:
         """The slab-layout copy of the weight the kernel reads (one per compute mode), rebuilt when
         the parameter is modified in place (optimizer step, load_state_dict) or moved (`.to(device)`)."""
         w = self.weight

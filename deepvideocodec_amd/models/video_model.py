@@ -499,13 +499,15 @@ class DMC(nn.Module):
     def set_precision(self, precision: str = "fp32"):
         """"fp32" (default): exact fp32 convolutions, the parity path.  "bf16": the 1x1 / 3x3
         convolutions round their operands to bf16 and accumulate in fp32 (3-4x faster, results differ
-        from the fp32 path; encoder and decoder must use the same setting).  Inference only: under
-        autograd the convolutions always run in fp32."""
-        if precision not in ("fp32", "bf16"):
+        from the fp32 path; encoder and decoder must use the same setting).  "bf16x2": operands split
+        into two bf16 parts (hi + lo, 16 mantissa bits), three bf16 matrix products per convolution
+        term.  Inference only: under autograd the convolutions always run in fp32."""
+        modes = {"fp32": 0, "bf16": 1, "bf16x2": 2}
+        if precision not in modes:
             raise ValueError(f"unknown precision {precision!r}")
         for m in self.modules():
             if isinstance(m, Conv2d):
-                m.compute_bf16 = precision == "bf16"
+                m.compute_bf16 = modes[precision]
         return self
 
     def aux_loss(self):

@@ -87,8 +87,10 @@ typedef struct DvcConv2d {
   const float* residual2;          /* NULL or a second tensor in output layout (needs residual) */
   int64_t res2_batch_stride, res2_chan_stride;
   int32_t compute_bf16;            /* 0: exact fp32 MFMA (weight_packed from dvc_conv2d_pack_weight);
-                                      1: operands rounded to bf16, fp32 accumulate (weight_packed from
-                                      dvc_conv2d_bf16_pack_weight; ksize 1 or 3 only) */
+                                      1: operands rounded to bf16, fp32 accumulate; 2: operands split
+                                      into two bf16 parts (16 mantissa bits), three bf16 MFMAs per
+                                      product, fp32 accumulate (weight_packed from
+                                      dvc_conv2d_bf16_pack_weight with parts = 1 / 2; ksize 1 or 3) */
   int32_t _pad;
 } DvcConv2d;
 
@@ -103,11 +105,12 @@ int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
 
-/* The same for the bf16 compute mode (a reduced-precision option, not the parity path): slabs are
- * [tap][8-channel octet 0/1][co][8 x bf16] per 16 input channels; the size is returned in 4-byte units. */
-int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
+/* The same for the bf16 compute modes: slabs are [part][tap][8-channel octet 0/1][co][8 x bf16] per 16
+ * input channels, parts = 1 (rounded) or 2 (hi + lo split); the size is returned in 4-byte units. */
+int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                             int32_t parts);
 int dvc_conv2d_bf16_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
-                                int32_t stride, float* packed, void* stream);
+                                int32_t stride, int32_t parts, float* packed, void* stream);
 
 /* Backward bilinear warp, border clamp, flow in pixels (ch0 = x, ch1 = y):
  * layers.py:175-198 (`torch_warp` = grid_sample(bilinear, border, align_corners=True)). */

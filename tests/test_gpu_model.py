@@ -335,6 +335,12 @@ def test_bf16_precision_option(seeded_sd):
     assert not torch.equal(rec16[0], rec32[0])                 # it really is a different arithmetic
     assert abs(bpp16 - bpp32) <= 0.03 * bpp32, (bpp16, bpp32)
     assert all(abs(a - b) <= 0.1 for a, b in zip(psnr16, psnr32)), (psnr16, psnr32)
+    net.set_precision("bf16x2")                                 # split operands: ~2^-17 per product
+    assert net.contextual_encoder.conv1._bf16() == 2
+    bpp2, psnr2, rec2 = run()
+    assert not torch.equal(rec2[0], rec32[0])
+    assert abs(bpp2 - bpp32) <= 2e-3 * bpp32, (bpp2, bpp32)
+    assert all(abs(a - b) <= 2e-3 for a, b in zip(psnr2, psnr32)), (psnr2, psnr32)
     net.set_precision("fp32")
     bpp_again, _, rec_again = run()
     assert bpp_again == bpp32 and torch.equal(rec_again[1], rec32[1])

@@ -387,3 +387,38 @@ def test_conv2d_bf16_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slop
     close(got, want, rel=2e-5)
     with pytest.raises(Exception):
         ops.conv2d(dev(torch.randn(1, 8, 16, 16)), dev(torch.randn(8, 8, 7, 7)), None, bf16=True)
+
+
+@pytest.mark.parametrize("k,stride,cins,cout,H,W,batch,in_slope,out_slope,shuffle", BF16_CASES)
+def test_conv2d_bf16_split_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle):
+    """The split mode: every operand is hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is
+    hi*hi + hi*lo + lo*hi, summed in fp32.  It must agree with that expression evaluated in fp64 to fp32
+    noise, and with the exact convolution to ~2^-16 per product."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(k * 37 + cout + H)
+    parts = [torch.randn(batch, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    x = torch.cat(parts, 1)
+    if in_slope is not None:
+        x = F.leaky_relu(x, in_slope)
+
+    def split(t):
+        hi = t.bfloat16().float()
+        return hi.double(), (t - hi).bfloat16().double()
+
+    xh, xl = split(x)
+    wh, wl = split(w)
+    conv = lambda u, v: F.conv2d(u, v, None, stride=stride, padding=k // 2)
+    want = conv(xh, wh) + conv(xh, wl) + conv(xl, wh) + b.double().view(1, -1, 1, 1)
+    exact = conv(x.double(), w.double()) + b.double().view(1, -1, 1, 1)
+    if out_slope is not None:
+        want, exact = F.leaky_relu(want, out_slope), F.leaky_relu(exact, out_slope)
+    if shuffle:
+        want, exact = F.pixel_shuffle(want, 2), F.pixel_shuffle(exact, 2)
+    res = torch.randn(want.shape, generator=g)
+    got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), stride=stride, in_slope=in_slope, out_slope=out_slope,
+                     pixel_shuffle=shuffle, residual=dev(res), bf16=2)
+    close(got, (want + res).float(), rel=2e-5)
+    assert (got.cpu().double() - (exact + res)).abs().max().item() < 2e-4

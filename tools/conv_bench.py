@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
-    ap.add_argument("--bf16", type=int, default=0, help="1: the reduced-precision bf16 compute mode (k 1/3 only)")
+    ap.add_argument("--bf16", type=int, default=0, help="1: bf16-rounded operands, 2: split bf16 hi + lo operands (k 1/3 only)")
     ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
     args = ap.parse_args()
     names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
@@ -64,7 +64,7 @@ def main():
         x = torch.randn(1, cin, h, w, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
-        bf = bool(args.bf16) and k != 7
+        bf = args.bf16 if k != 7 else 0
         packed = ops.pack_conv_weight(wt, s, bf16=bf)
         out = ops.conv2d(x, wt, b, stride=s, packed=packed, bf16=bf)
         for _ in range(2):
