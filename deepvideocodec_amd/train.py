@@ -3,6 +3,8 @@
   RateDistortionLoss        dmc/train.py:96-211   (collect_likelihoods_list :74-93)
   configure_optimizers      dmc/train.py:251-282  (main / aux split by the `.quantiles` suffix)
   stage_of_epoch, train_step dmc/train.py:285-346 (six-stage schedule, clip, two optimizer steps)
+  train_one_epoch, test_epoch, save_checkpoint, load_checkpoint, fit
+                            dmc/train.py:285-403,597-655 (epoch loop, checkpoint dict, MultiStepLR)
 
 The reductions of the loss (sum of log-likelihoods per sample, squared error per sample) are the
 HIP reduction kernels with their adjoints; what is left to torch is arithmetic on (N,)-vectors.
@@ -185,3 +187,137 @@ def train_step(net, criterion: RateDistortionLoss, frames: Sequence[Tensor], opt
     aux_optimizer.step()
     return {"loss": out["loss"].item(), "mse_loss": out["mse_loss"].item(), "bpp_loss": out["bpp_loss"].item(),
             "aux_loss": aux_loss.item()}
+
+
+class AverageMeter:
+    """Running average (dmc/train.py:214-227)."""
+
+    def __init__(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n: int = 1):
+        self.val = float(val)
+        self.sum += float(val) * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def train_one_epoch(epoch: int, net_intra, net, criterion: RateDistortionLoss, dataloader, optimizer, aux_optimizer,
+                    clip_max_norm: float = 1.0, log=None, log_every: int = 100) -> Dict[str, float]:
+    """dmc/train.py:285-346: one pass over `dataloader` (each batch a list of T frame tensors) in training
+    mode; the stage (which sub-networks run, which loss is back-propagated) follows from `epoch`.
+    Returns the epoch's average losses."""
+    net.train()
+    device = next(net.parameters()).device
+    meters = {k: AverageMeter() for k in ("loss", "mse_loss", "bpp_loss", "aux_loss")}
+    sampler = getattr(dataloader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):        # per-epoch reshuffle of a DistributedSampler
+        sampler.set_epoch(epoch)
+    for i, batch in enumerate(dataloader):
+        frames = [f.to(device, non_blocking=True) for f in batch]
+        stats = train_step(net, criterion, frames, optimizer, aux_optimizer, clip_max_norm, epoch, net_intra)
+        for k, m in meters.items():
+            m.update(stats[k])
+        if log is not None and i % log_every == 0:
+            log(f"Train epoch {epoch}: [{i * len(frames[0])}/{_dataset_len(dataloader)}] "
+                f"Loss: {stats['loss']:.3f} | MSE loss: {stats['mse_loss']:.5f} | "
+                f"Bpp loss: {stats['bpp_loss']:.4f} | Aux loss: {stats['aux_loss']:.2f}")
+    return {k: m.avg for k, m in meters.items()}
+
+
+def _dataset_len(dataloader) -> int:
+    ds = getattr(dataloader, "dataset", None)
+    try:
+        return len(ds) if ds is not None else len(dataloader)
+    except TypeError:
+        return -1
+
+
+def test_epoch(epoch: int, dataloader, net_intra, net, criterion: RateDistortionLoss, log=None) -> float:
+    """dmc/train.py:349-398: evaluation-mode pass with the epoch's stage flags; returns the average loss,
+    reduced over the ranks of the process group when there is one (every rank then sees the same value,
+    so `is_best` and the learning-rate schedule agree across ranks)."""
+    net.eval()
+    device = next(net.parameters()).device
+    meters = {k: AverageMeter() for k in ("loss", "mse_loss", "bpp_loss", "aux_loss")}
+    motion_pretrain, frame_pretrain, _ = stage_of_epoch(epoch)
+    with torch.no_grad():
+        for batch in dataloader:
+            frames = [f.to(device, non_blocking=True) for f in batch]
+            if epoch >= 50 and net_intra is not None:
+                frames[0] = net_intra(frames[0])["x_hat"]
+            out = criterion(net(frames, motion_pretrain=motion_pretrain, frame_pretrain=frame_pretrain), frames[1:])
+            meters["aux_loss"].update(float(sum(net.aux_loss())))
+            for k in ("loss", "mse_loss", "bpp_loss"):
+                meters[k].update(float(out[k]))
+    sums = torch.tensor([meters[k].sum for k in ("loss", "mse_loss", "bpp_loss", "aux_loss")] + [meters["loss"].count],
+                        dtype=torch.float64)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        sums = sums.to(device) if dist.get_backend() == "nccl" else sums
+        dist.all_reduce(sums)
+        sums = sums.cpu()
+    avg = (sums[:4] / sums[4].clamp(min=1)).tolist()
+    if log is not None:
+        log(f"Test epoch {epoch}: Average losses: Loss: {avg[0]:.3f} | MSE loss: {avg[1]:.5f} | "
+            f"Bpp loss: {avg[2]:.4f} | Aux loss: {avg[3]:.2f}")
+    return avg[0]
+
+
+def checkpoint_state(epoch: int, net, loss: float, optimizer, aux_optimizer, lr_scheduler) -> dict:
+    """The dict dmc/train.py:644-652 saves (same keys)."""
+    return {"epoch": epoch, "state_dict": net.state_dict(), "loss": loss, "optimizer": optimizer.state_dict(),
+            "aux_optimizer": aux_optimizer.state_dict(), "lr_scheduler": lr_scheduler.state_dict()}
+
+
+def save_checkpoint(state: dict, is_best: bool, base_dir: str, filename: str = "checkpoint.pth.tar") -> str:
+    """dmc/train.py:400-403 (the path is joined properly rather than concatenated)."""
+    import os
+    import shutil
+    os.makedirs(base_dir, exist_ok=True)
+    path = os.path.join(base_dir, filename)
+    tmp = path + ".tmp"
+    torch.save(state, tmp)
+    os.replace(tmp, path)           # a crash mid-write leaves the previous checkpoint intact
+    if is_best:
+        shutil.copyfile(path, os.path.join(base_dir, "checkpoint_best_loss.pth.tar"))
+    return path
+
+
+def load_checkpoint(path: str, net, optimizer=None, aux_optimizer=None, lr_scheduler=None, map_location="cpu") -> int:
+    """Resume (dmc/train.py:609-616): loads the model and, when given, the optimizer / scheduler states
+    (the reference leaves those three commented out); returns the epoch to continue from.  Tensors only
+    (`weights_only=True`): nothing in the file is executed."""
+    ck = torch.load(path, map_location=map_location, weights_only=True)
+    net.load_state_dict(ck["state_dict"])
+    for obj, key in ((optimizer, "optimizer"), (aux_optimizer, "aux_optimizer"), (lr_scheduler, "lr_scheduler")):
+        if obj is not None and key in ck:
+            obj.load_state_dict(ck[key])
+    return int(ck["epoch"]) + 1
+
+
+def fit(net, train_loader, test_loader, epochs: int, lmbda: float = 2048.0, learning_rate: float = 1e-4,
+        aux_learning_rate: float = 1e-3, clip_max_norm: float = 1.0, net_intra=None, save_dir: Optional[str] = None,
+        checkpoint: Optional[str] = None, log=None) -> Dict[str, float]:
+    """The epoch loop of dmc/train.py:597-655: dual Adam, MultiStepLR(milestones=[300], gamma=0.1),
+    train pass, test pass, best-loss tracking, checkpoint per epoch (written by rank 0 only)."""
+    import torch.distributed as dist
+    optimizer, aux_optimizer = configure_optimizers(net, learning_rate, aux_learning_rate)
+    lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[300], gamma=0.1)
+    criterion = RateDistortionLoss(lmbda=lmbda, return_details=True)
+    first = load_checkpoint(checkpoint, net) if checkpoint else 0
+    rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    best, last = float("inf"), {}
+    for epoch in range(first, epochs):
+        if log is not None:
+            log(f"======Current epoch {epoch} ======  Learning rate: {optimizer.param_groups[0]['lr']}")
+        last = train_one_epoch(epoch, net_intra, net, criterion, train_loader, optimizer, aux_optimizer,
+                               clip_max_norm, log)
+        loss = test_epoch(epoch, test_loader, net_intra, net, criterion, log)
+        lr_scheduler.step()
+        is_best, best = loss < best, min(loss, best)
+        last.update({"test_loss": loss, "best_loss": best, "epoch": epoch})
+        if save_dir and rank0:
+            save_checkpoint(checkpoint_state(epoch, net, loss, optimizer, aux_optimizer, lr_scheduler), is_best, save_dir)
+    return last

@@ -208,3 +208,28 @@ def test_train_step_stages(seeded_sd):
         stats = TR.train_step(net, crit, frames, opt, aux_opt, clip_max_norm=1.0, epoch=epoch)
         assert all(math.isfinite(v) for v in stats.values()), (epoch, stats)
     assert not torch.equal(net.contextual_encoder.conv1.weight.detach(), w_frame)
+
+
+def test_fit_epoch_loop_and_resume(seeded_sd, tmp_path):
+    """The epoch loop of dmc/train.py:597-655 on the device: train pass + test pass per epoch, the
+    checkpoint dict with the reference's keys, and a resume that restores the weights."""
+    from deepvideocodec_amd import train as TR
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda()
+    loader = lambda seeds: [synthetic_gop(3, 64, 64, seed=s, batch=2) for s in seeds]
+    logs = []
+    res = TR.fit(net, loader((1, 2)), loader((3,)), epochs=1, save_dir=str(tmp_path), log=logs.append)
+    assert res["epoch"] == 0 and all(math.isfinite(res[k]) for k in ("loss", "mse_loss", "bpp_loss", "aux_loss", "test_loss"))
+    assert not net.training                                   # the epoch ends with the evaluation pass
+    ck = torch.load(tmp_path / "checkpoint.pth.tar", weights_only=True)
+    assert set(ck) == {"epoch", "state_dict", "loss", "optimizer", "aux_optimizer", "lr_scheduler"}
+    net2 = DMC().cuda()
+    assert TR.load_checkpoint(str(tmp_path / "checkpoint.pth.tar"), net2) == 1
+    sd1, sd2 = net.state_dict(), net2.state_dict()
+    assert sd1.keys() == sd2.keys() and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    # the resumed model evaluates to the same loss
+    crit = TR.RateDistortionLoss(lmbda=2048.0, return_details=True)
+    assert TR.test_epoch(0, loader((3,)), None, net2, crit) == pytest.approx(res["test_loss"], rel=1e-6)

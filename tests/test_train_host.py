@@ -104,3 +104,67 @@ def test_all_reduce_gradients_gloo_world2():
         for a, b in zip(rank_grads, want):
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     assert T.all_reduce_gradients(net.parameters()) == 0   # no process group: no-op
+
+
+class _TinyCodec(torch.nn.Module):
+    """CPU stand-in with the DMC training interface (forward over a frame list, aux_loss, a
+    `.quantiles` parameter) so the epoch / checkpoint logic can be exercised without a GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 3, 3, padding=1)
+        self.eb = torch.nn.Module()
+        self.eb.quantiles = torch.nn.Parameter(torch.tensor([[[-1.0, 0.0, 1.0]]]))
+        self.calls = []
+
+    def forward(self, frames, motion_pretrain=False, frame_pretrain=False):
+        if not isinstance(frames, list):
+            raise RuntimeError("frames must be a list")
+        self.calls.append((self.training, motion_pretrain, frame_pretrain))
+        x_hat, liks = [], []
+        for x in frames[1:]:
+            y = self.conv(x)
+            lik = torch.sigmoid(y.mean(dim=1, keepdim=True)) * 0.9 + 0.05
+            x_hat.append(y)
+            liks.append({"motion": {"y": lik, "z": lik[:, :, ::4, ::4]}, "frame": {"y": lik, "z": lik[:, :, ::4, ::4]}})
+        return {"x_hat": x_hat, "likelihoods": liks}
+
+    def aux_loss(self):
+        return [(self.eb.quantiles - torch.tensor([[[-2.0, 0.0, 2.0]]])).abs().sum()]
+
+
+def _loader(n_batches, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [[torch.rand(2, 3, 16, 16, generator=g) for _ in range(3)] for _ in range(n_batches)]
+
+
+def test_epoch_loop_and_checkpoints(tmp_path):
+    torch.manual_seed(0)
+    net = _TinyCodec()
+    logs = []
+    res = T.fit(net, _loader(3, 1), _loader(2, 2), epochs=2, lmbda=256.0, save_dir=str(tmp_path), log=logs.append)
+    # stage flags of epochs 0-1 (motion pre-training) reach the model in both modes: 3 train + 2 test per epoch
+    assert net.calls == ([(True, True, False)] * 3 + [(False, True, False)] * 2) * 2
+    assert res["epoch"] == 1 and res["best_loss"] <= res["test_loss"] and math.isfinite(res["loss"])
+    assert any(s.startswith("Test epoch 1") for s in logs) and any(s.startswith("Train epoch 0") for s in logs)
+    ck = torch.load(tmp_path / "checkpoint.pth.tar", weights_only=True)
+    assert set(ck) == {"epoch", "state_dict", "loss", "optimizer", "aux_optimizer", "lr_scheduler"} and ck["epoch"] == 1
+    assert (tmp_path / "checkpoint_best_loss.pth.tar").exists()
+    # resume: weights and optimizer state restored, loop continues at epoch 2
+    net2 = _TinyCodec()
+    opt, aux = T.configure_optimizers(net2)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[300], gamma=0.1)
+    assert T.load_checkpoint(str(tmp_path / "checkpoint.pth.tar"), net2, opt, aux, sched) == 2
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    assert opt.state_dict()["state"][0]["step"] == 6          # 2 epochs x 3 batches
+    res2 = T.fit(net2, _loader(1, 3), _loader(1, 4), epochs=3, checkpoint=str(tmp_path / "checkpoint.pth.tar"))
+    assert res2["epoch"] == 2
+    # the quantile parameters are moved by the auxiliary optimizer only
+    assert not torch.equal(net.eb.quantiles, torch.tensor([[[-1.0, 0.0, 1.0]]]))
+
+
+def test_average_meter():
+    m = T.AverageMeter()
+    m.update(2.0)
+    m.update(4.0, n=3)
+    assert m.val == 4.0 and m.count == 4 and m.avg == pytest.approx(3.5)
