@@ -84,7 +84,7 @@ SIGNATURES = {
     "dvc_likelihood_bits": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _P]),
     "dvc_sq_err_sum": (C.c_int, [_SRC, _SRC, _i32, _i32, _i32, _P, _P, _P]),
     "dvc_conv2d_wgrad_scratch_floats": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
-    "dvc_conv2d_wgrad": (C.c_int, [_SRC, _i32, _i32, _i32, _i32, _i32, _f32, _P, _i32, _i32, _i32, _P, _P, _P]),
+    "dvc_conv2d_wgrad": (C.c_int, [_SRC, _i32, _i32, _i32, _i32, _i32, _f32, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "dvc_act_grad": (C.c_int, [_SRC, _SRC, _f32, _i32, _P, _i32, _i32, _i32, _i32, _P]),
     "dvc_mul_act_grad": (C.c_int, [_SRC, _SRC, _f32, _DST, _i32, _i32, _i32, _P]),
     "dvc_zero_upsample2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _i32, _i32, _P]),

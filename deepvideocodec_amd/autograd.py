@@ -50,8 +50,13 @@ class _Conv2d(torch.autograd.Function):
         else:
             g_pre = ops.act_grad(g, out, 1.0 if out_slope is None else out_slope, ps, (n, cout, ho, wo))
         need = ctx.needs_input_grad
-        gw = ops.conv2d_wgrad(srcs, g_pre, weight.shape, stride, in_slope) if need[0] else None
-        gb = ops.plane_dot(g_pre, None, sum_batch=True) if (has_bias and need[1]) else None
+        gw = gb = None
+        if need[0] and has_bias and need[1]:     # the bias gradient rides along with the weight gradient
+            gw, gb = ops.conv2d_wgrad(srcs, g_pre, weight.shape, stride, in_slope, with_bias=True)
+        elif need[0]:
+            gw = ops.conv2d_wgrad(srcs, g_pre, weight.shape, stride, in_slope)
+        elif has_bias and need[1]:
+            gb = ops.plane_dot(g_pre, None, sum_batch=True)
         gsrcs = [None] * len(srcs)
         if any(need[7:]):
             # data gradient = stride-1 convolution of (zero-upsampled) g_pre with the flipped,

@@ -334,9 +334,11 @@ def sq_err_sum(a: Tensor, b: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------ gradients
-def conv2d_wgrad(srcs: Srcs, grad_pre: Tensor, wshape, stride: int = 1, in_slope: Optional[float] = None) -> Tensor:
+def conv2d_wgrad(srcs: Srcs, grad_pre: Tensor, wshape, stride: int = 1, in_slope: Optional[float] = None,
+                 with_bias: bool = False):
     """Weight gradient (OIHW) of conv2d; grad_pre = contiguous (N, Cout, ho, wo) gradient before the
-    output activation (see act_grad)."""
+    output activation (see act_grad).  `with_bias`: also return the bias gradient (sum of grad_pre over
+    batch and pixels, from the same pass) as a second tensor."""
     if isinstance(srcs, torch.Tensor):
         srcs = (srcs,)
     cout, cin, k, _ = wshape
@@ -350,10 +352,12 @@ def conv2d_wgrad(srcs: Srcs, grad_pre: Tensor, wshape, stride: int = 1, in_slope
     nfl = check(lib.dvc_conv2d_wgrad_scratch_floats(cout, cin, k, stride, n, h, w), "dvc_conv2d_wgrad_scratch_floats")
     scratch = torch.empty(nfl, dtype=torch.float32, device=grad_pre.device)
     gw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=grad_pre.device)
+    gb = torch.empty(cout, dtype=torch.float32, device=grad_pre.device) if with_bias else None
     check(lib.dvc_conv2d_wgrad(arr, len(srcs), n, h, w, 0 if in_slope is None else 1,
                                1.0 if in_slope is None else float(in_slope), grad_pre.data_ptr(), cout, k, stride,
-                               scratch.data_ptr(), gw.data_ptr(), _stream()), "dvc_conv2d_wgrad")
-    return gw
+                               scratch.data_ptr(), gw.data_ptr(), gb.data_ptr() if with_bias else None, _stream()),
+          "dvc_conv2d_wgrad")
+    return (gw, gb) if with_bias else gw
 
 
 def act_grad(grad: Tensor, act_out: Optional[Tensor], slope: float, pixel_shuffle: bool, conv_shape) -> Tensor:

@@ -231,13 +231,15 @@ int dvc_sq_err_sum(const DvcSrc* a, const DvcSrc* b, int32_t batch, int32_t h, i
  *   gW[co][ci][ky][kx] = sum_{n,oy,ox} grad_out[n][co][oy][ox] * act_in(cat(srcs))[n][ci][oy*s+ky-p][ox*s+kx-p]
  * grad_out is the gradient before the output activation, contiguous (N, Cout, ho, wo) -- see
  * dvc_act_grad.  scratch needs dvc_conv2d_wgrad_scratch_floats() floats; grad_weight is OIHW.
- * Deterministic (fixed summation order).
+ * grad_bias (Cout floats, or NULL to skip) receives the bias gradient sum_{n,oy,ox} grad_out[n][co][oy][ox]
+ * from the same pass over grad_out.  Deterministic (fixed summation order).
  */
 int64_t dvc_conv2d_wgrad_scratch_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
                                         int32_t batch, int32_t in_h, int32_t in_w);
 int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch, int32_t in_h, int32_t in_w,
                      int32_t in_act, float in_slope, const float* grad_out, int32_t out_channels,
-                     int32_t ksize, int32_t stride, float* scratch, float* grad_weight, void* stream);
+                     int32_t ksize, int32_t stride, float* scratch, float* grad_weight, float* grad_bias,
+                     void* stream);
 /* grad_pre (contiguous N, C, ho, wo) = grad * act'(act_out), act'(t) = t > 0 ? 1 : slope, with
  * grad / act_out in the stored layout (PixelShuffle(2)-ed when pixel_shuffle); act_out NULL = no
  * activation (pure un-shuffle / compaction).  LeakyReLU / ReLU / PixelShuffle backward. */

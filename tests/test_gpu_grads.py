@@ -33,6 +33,8 @@ GRAD_CONV_CASES = [
     (3, 2, (16,), 24, 25, 31, 2, 0.01, 0.1, False),
     (7, 1, (8,), 32, 30, 50, 1, None, 0.0, False),
     (7, 1, (16,), 2, 20, 37, 2, None, None, False),
+    (7, 1, (32,), 64, 19, 70, 2, None, 0.0, False),      # two output-channel blocks, ragged rows and columns
+    (7, 1, (40, 24), 16, 9, 33, 1, 0.1, None, False),    # two input-channel blocks over two sources
     (1, 1, (64,), 32, 33, 47, 1, None, None, False),
     (1, 2, (12,), 64, 34, 50, 2, None, None, False),
     (3, 1, (24,), 32, 10, 14, 2, None, 0.01, True),
@@ -89,14 +91,16 @@ def test_conv2d_wgrad_large_reduction():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 64, 256, 256, generator=g)
     w = torch.randn(64, 64, 3, 3, generator=g) / 24
-    cx, cw = x.clone().requires_grad_(), w.clone().requires_grad_()
-    y_ref = F.conv2d(cx, cw, None, padding=1)
-    R = torch.randn(y_ref.shape, generator=g) / 64
+    b = torch.randn(64, generator=g)
+    cx, cw, cb = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = F.conv2d(cx, cw, cb, padding=1)
+    R = torch.randn(y_ref.shape, generator=g) / 64 + 0.01
     (y_ref * R).sum().backward()
-    gx, gw = dev(x).requires_grad_(), dev(w).requires_grad_()
-    y = A.conv2d(gx, gw, None)
+    gx, gw, gb = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+    y = A.conv2d(gx, gw, gb)
     (y * dev(R)).sum().backward()
     close(gw.grad, cw.grad, rel=5e-4, what="grad weight")
+    close(gb.grad, cb.grad, rel=5e-4, what="grad bias")      # summed in the weight-gradient pass
     close(gx.grad, cx.grad, what="grad x")
 
 

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
     ap.add_argument("--bf16", type=int, default=0, help="1: bf16-rounded operands, 2: split bf16 hi + lo operands (k 1/3 only)")
+    ap.add_argument("--wgrad", type=int, default=0, help="1: time the weight-gradient kernel of the shape instead")
+    ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
     args = ap.parse_args()
     names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
@@ -61,10 +63,28 @@ def main():
     total_t = total_f = 0.0
     for name in names:
         k, s, cin, cout, h, w = SHAPES[name]
-        x = torch.randn(1, cin, h, w, device="cuda")
+        x = torch.randn(args.batch, cin, h, w, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
         bf = args.bf16 if k != 7 else 0
+        if args.wgrad:
+            ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+            g = torch.randn(args.batch, cout, ho, wo, device="cuda")
+            for _ in range(2):
+                ops.conv2d_wgrad(x, g, wt.shape, s, with_bias=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                ops.conv2d_wgrad(x, g, wt.shape, s, with_bias=True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            flops = 2.0 * args.batch * cout * ho * wo * cin * k * k
+            print(f"{name:14s} wgrad k{k} s{s} {cin:4d}->{cout:4d} @{args.batch}x{h}x{w}: {ms * 1e3:9.1f} us  "
+                  f"{flops / ms / 1e9:7.1f} TFLOP/s")
+            total_t += ms
+            total_f += flops
+            continue
         packed = ops.pack_conv_weight(wt, s, bf16=bf)
         out = ops.conv2d(x, wt, b, stride=s, packed=packed, bf16=bf)
         for _ in range(2):
@@ -76,7 +96,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
-        flops = 2.0 * cout * out.shape[2] * out.shape[3] * cin * k * k
+        flops = 2.0 * args.batch * cout * out.shape[2] * out.shape[3] * cin * k * k
         print(f"{name:14s} k{k} s{s} {cin:4d}->{cout:4d} @{h}x{w}: {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s")
         total_t += ms
         total_f += flops
