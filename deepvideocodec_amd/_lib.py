@@ -46,7 +46,7 @@ class DvcConv2d(C.Structure):
         ("res_scale", C.c_void_p),
         ("residual2", C.c_void_p),
         ("res2_batch_stride", C.c_int64), ("res2_chan_stride", C.c_int64),
-        ("compute_bf16", C.c_int32), ("_pad", C.c_int32),
+        ("precision", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -60,8 +60,8 @@ SIGNATURES = {
     "dvc_conv2d": (C.c_int, [C.POINTER(DvcConv2d), _P]),
     "dvc_conv2d_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "dvc_conv2d_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
-    "dvc_conv2d_bf16_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32, _i32]),
-    "dvc_conv2d_bf16_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
+    "dvc_conv2d_reduced_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "dvc_conv2d_reduced_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
     "dvc_flow_warp": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_avg_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _P]),
     "dvc_max_pool2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),

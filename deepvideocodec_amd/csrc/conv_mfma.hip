@@ -30,6 +30,23 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 16-bit operand element of the reduced-operand modes: bf16 (modes 1, 2) or fp16 (mode 3).  The fp16
+// conversion saturates instead of overflowing to infinity.
+template <bool F16> struct Half16 { using T = __bf16; using V8 = bf16x8; };
+template <> struct Half16<true> { using T = _Float16; using V8 = f16x8; };
+template <bool F16>
+__device__ __forceinline__ typename Half16<F16>::T to_half16(float v) {
+  if constexpr (F16) return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+  else return (__bf16)v;
+}
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 struct ConvArgs {
   DvcSrc src[DVC_MAX_SRC];
@@ -65,7 +82,8 @@ constexpr int slab_floats(int ks, int s, int cb) { return (chunk_of(ks, s) * ks 
 constexpr int BF_CK = 16;
 constexpr int slab_floats_bf16(int ks, int cb) { return (ks * ks * 2 * cb * 4 + 255) / 256 * 256; }
 
-__global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* w, __bf16* packed, int cout, int cin, int ks,
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_weight_half_kernel(const float* w, typename Half16<F16>::T* packed, int cout, int cin, int ks,
                                                                int cb, int part_elems, int parts, int nchunks,
                                                                long long total) {
   const int taps = ks * ks;
@@ -81,8 +99,8 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* w, _
     const int ci = chunk * BF_CK + o * 8 + e8, co = blk * cb + col;
     float v = 0.f;
     if (tap < taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
-    const __bf16 hi = (__bf16)v;
-    packed[i] = part == 0 ? hi : (__bf16)(v - (float)hi);
+    const auto hi = to_half16<F16>(v);
+    packed[i] = part == 0 ? hi : to_half16<F16>(v - (float)hi);
   }
 }
 
@@ -113,12 +131,16 @@ constexpr int min_waves_per_simd() { return 2; }
 // a product taken as hi*hi + hi*lo + lo*hi on the same MFMA: three bf16 MFMAs per 16 channels instead of
 // eight fp32 ones, relative error of a product <= ~2^-16.  With two parts the operand tiles are twice as
 // large and the LDS buffers are single (the next chunk is staged after the MFMA phase, not during it).
+// 3 = the same split with fp16 parts on v_mfma_f32_32x32x16_f16: hi = fp16(v), lo = fp16(v - hi) carry 22
+// significant bits (absolute floor 2^-25 from the fp16 subnormals, which the MFMA keeps), so a product is
+// within ~2^-21 of the fp32 one; operands saturate at +-65504 (hi) + 65504 (lo).
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 struct Geo {
   static_assert(!HALF || MT == 1, "half blocks are 32 channels");
-  static_assert(!BF || KS != 7, "the bf16 modes cover the 1x1 and 3x3 layers");
-  static constexpr int PARTS = BF ? BF : 1;
-  static constexpr int NBUF = BF == 2 ? 1 : 2;   // LDS buffers per operand
+  static_assert(!BF || KS != 7, "the reduced-operand modes cover the 1x1 and 3x3 layers");
+  static constexpr int PARTS = BF >= 2 ? 2 : 1;
+  static constexpr bool F16 = BF == 3;
+  static constexpr int NBUF = PARTS == 2 ? 1 : 2;   // LDS buffers per operand
   static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
@@ -274,17 +296,18 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     }
     if constexpr (BF) {
       // element i of the tile gets its 16 channels as two 16-byte octets: [octet][i][8 x bf16]
-      bf16x8* const d8 = reinterpret_cast<bf16x8*>(in_s + buf * IN_BUF) + tid;
+      using V8 = typename Half16<G::F16>::V8;
+      V8* const d8 = reinterpret_cast<V8*>(in_s + buf * IN_BUF) + tid;
 #pragma unroll
       for (int j = 0; j < IN_PT; ++j)
         if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) {
 #pragma unroll
           for (int o = 0; o < 2; ++o) {
-            bf16x8 hi, lo;
+            V8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              hi[e] = (__bf16)rin[8 * o + e][j];
-              if constexpr (PARTS == 2) lo[e] = (__bf16)(rin[8 * o + e][j] - (float)hi[e]);
+              hi[e] = to_half16<G::F16>(rin[8 * o + e][j]);
+              if constexpr (PARTS == 2) lo[e] = to_half16<G::F16>(rin[8 * o + e][j] - (float)hi[e]);
             }
             d8[o * CHS + 256 * j] = hi;
             if constexpr (PARTS == 2) d8[(2 + o) * CHS + 256 * j] = lo;   // [part][octet][element]
@@ -328,10 +351,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       prefetch_input((k + 1) * CK);
     }
     if constexpr (BF) {
-      const bf16x8* bbase = reinterpret_cast<const bf16x8*>(in_s + cur * IN_BUF) + b_lane8;
-      const bf16x8* abase = reinterpret_cast<const bf16x8*>(w_s + cur * SLAB) + a_lane8;
+      using V8 = typename Half16<G::F16>::V8;
+      const V8* bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
+      const V8* abase = reinterpret_cast<const V8*>(w_s + cur * SLAB) + a_lane8;
       if constexpr (PARTS == 1) {
-        bf16x8 av[2][MT], bv[2][NT];
+        V8 av[2][MT], bv[2][NT];
         auto fetch = [&](int tap, int slot) {
           const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
@@ -347,7 +371,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = mfma16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt]);
         }
       } else {
         // split operands: A parts [part][tap][octet][co], B parts [part][octet][element]; the small
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
           const int ky = t / KS, kx = t - ky * KS;
-          bf16x8 ah[MT], al[MT];
+          V8 ah[MT], al[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             ah[mt] = abase[t * 2 * CBP + mt * 32];
@@ -364,13 +388,13 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8 bh = bbase[(nt * SL + ky) * IW + kx];
-            const bf16x8 bl = bbase[BPART + (nt * SL + ky) * IW + kx];
+            const V8 bh = bbase[(nt * SL + ky) * IW + kx];
+            const V8 bl = bbase[BPART + (nt * SL + ky) * IW + kx];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
+              acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
+              acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
             }
           }
         }
@@ -677,29 +701,35 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
   return dvc::check_launch("pack_weight_kernel");
 }
 
-extern "C" int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
-                                                        int32_t parts) {
-  if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_packed_weight_floats")) return DVC_EINVAL;
-  if (ksize == 7 || parts < 1 || parts > 2) {
-    dvc::set_error("dvc_conv2d_bf16_packed_weight_floats: the bf16 modes cover ksize 1 and 3, parts 1 or 2");
+extern "C" int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                                           int32_t precision) {
+  if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_reduced_packed_weight_floats")) return DVC_EINVAL;
+  if (ksize == 7 || precision < DVC_PRECISION_BF16 || precision > DVC_PRECISION_FP16X2) {
+    dvc::set_error("dvc_conv2d_reduced_packed_weight_floats: precision 1..3, ksize 1 or 3");
     return DVC_EINVAL;
   }
-  const int cb = cout_block_of(cout);
+  const int cb = cout_block_of(cout), parts = precision == DVC_PRECISION_BF16 ? 1 : 2;
   return (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK) * parts * slab_floats_bf16(ksize, cb);
 }
 
-extern "C" int dvc_conv2d_bf16_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize,
-                                           int32_t stride, int32_t parts, float* packed, void* stream) {
-  if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_bf16_pack_weight")) return rc;
-  DVC_REQUIRE(ksize != 7 && parts >= 1 && parts <= 2, "dvc_conv2d_bf16_pack_weight: the bf16 modes cover ksize 1 and 3, parts 1 or 2");
-  DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_bf16_pack_weight: null pointer");
-  DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_bf16_pack_weight: packed buffer must be 16-byte aligned");
-  const int cb = cout_block_of(cout);
+extern "C" int dvc_conv2d_reduced_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize,
+                                              int32_t stride, int32_t precision, float* packed, void* stream) {
+  if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_reduced_pack_weight")) return rc;
+  DVC_REQUIRE(ksize != 7 && precision >= DVC_PRECISION_BF16 && precision <= DVC_PRECISION_FP16X2,
+              "dvc_conv2d_reduced_pack_weight: precision 1..3, ksize 1 or 3");
+  DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_reduced_pack_weight: null pointer");
+  DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_reduced_pack_weight: packed buffer must be 16-byte aligned");
+  const int cb = cout_block_of(cout), parts = precision == DVC_PRECISION_BF16 ? 1 : 2;
   const int part_elems = 2 * slab_floats_bf16(ksize, cb), nchunks = (cin + BF_CK - 1) / BF_CK;
   const long long total = (long long)((cout + cb - 1) / cb) * nchunks * part_elems * parts;
-  hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     weight, reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, part_elems, parts, nchunks, total);
-  return dvc::check_launch("pack_weight_bf16_kernel");
+  const dim3 grid(dvc::stream_grid(total, 256));
+  if (precision == DVC_PRECISION_FP16X2)
+    hipLaunchKernelGGL(pack_weight_half_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, weight,
+                       reinterpret_cast<_Float16*>(packed), cout, cin, ksize, cb, part_elems, parts, nchunks, total);
+  else
+    hipLaunchKernelGGL(pack_weight_half_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, weight,
+                       reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, part_elems, parts, nchunks, total);
+  return dvc::check_launch("pack_weight_half_kernel");
 }
 
 extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
@@ -773,17 +803,24 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   a.in_act = p->in_act ? 1 : 0;
   a.out_act = p->out_act ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (p->compute_bf16) {
-    DVC_REQUIRE(p->ksize != 7 && (p->compute_bf16 == 1 || p->compute_bf16 == 2),
-                "dvc_conv2d: the bf16 modes (1: rounded, 2: split) cover ksize 1 and 3");
-    if (p->compute_bf16 == 1) {
-      if (p->ksize == 3)
-        return p->stride == 1 ? dispatch_tile<3, 1, 1>(a, p->batch, st) : dispatch_tile<3, 2, 1>(a, p->batch, st);
-      return p->stride == 1 ? dispatch_tile<1, 1, 1>(a, p->batch, st) : dispatch_tile<1, 2, 1>(a, p->batch, st);
+  if (p->precision != DVC_PRECISION_FP32) {
+    DVC_REQUIRE(p->ksize != 7 && p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,
+                "dvc_conv2d: precision %d unknown, or a reduced-operand mode with ksize 7", p->precision);
+    const int key = p->precision * 100 + p->ksize * 10 + p->stride;
+    switch (key) {
+      case 131: return dispatch_tile<3, 1, 1>(a, p->batch, st);
+      case 132: return dispatch_tile<3, 2, 1>(a, p->batch, st);
+      case 111: return dispatch_tile<1, 1, 1>(a, p->batch, st);
+      case 112: return dispatch_tile<1, 2, 1>(a, p->batch, st);
+      case 231: return dispatch_tile<3, 1, 2>(a, p->batch, st);
+      case 232: return dispatch_tile<3, 2, 2>(a, p->batch, st);
+      case 211: return dispatch_tile<1, 1, 2>(a, p->batch, st);
+      case 212: return dispatch_tile<1, 2, 2>(a, p->batch, st);
+      case 331: return dispatch_tile<3, 1, 3>(a, p->batch, st);
+      case 332: return dispatch_tile<3, 2, 3>(a, p->batch, st);
+      case 311: return dispatch_tile<1, 1, 3>(a, p->batch, st);
+      default: return dispatch_tile<1, 2, 3>(a, p->batch, st);
     }
-    if (p->ksize == 3)
-      return p->stride == 1 ? dispatch_tile<3, 1, 2>(a, p->batch, st) : dispatch_tile<3, 2, 2>(a, p->batch, st);
-    return p->stride == 1 ? dispatch_tile<1, 1, 2>(a, p->batch, st) : dispatch_tile<1, 2, 2>(a, p->batch, st);
   }
   if (p->ksize == 3) return p->stride == 1 ? dispatch_tile<3, 1>(a, p->batch, st) : dispatch_tile<3, 2>(a, p->batch, st);
   if (p->ksize == 1) return p->stride == 1 ? dispatch_tile<1, 1>(a, p->batch, st) : dispatch_tile<1, 2>(a, p->batch, st);

@@ -35,22 +35,22 @@ class Conv2d(nn.Module):
         nn.init.constant_(self.bias, 0.01)
 
         self._packed = {}         # compute mode -> (key, kernel-layout image of `weight`)
-        # inference-only option: operands rounded to bf16, fp32 accumulation (1x1 / 3x3 kernels; the
+        # inference-only option: 16-bit operand arithmetic, fp32 accumulation (1x1 / 3x3 kernels; the
         # 7x7 motion-estimation layers always stay exact fp32).  See DMC.set_precision().
-        self.compute_bf16 = 0   # 0 exact fp32, 1 bf16-rounded operands, 2 split bf16 hi + lo operands
+        self.precision = 0      # ops.PRECISIONS: 0 exact fp32, 1 bf16, 2 bf16 hi + lo split, 3 fp16 hi + lo split
 
-    def _bf16(self) -> int:
-        return int(self.compute_bf16) if self.kernel_size != 7 else 0
+    def _precision(self) -> int:
+        return int(self.precision) if self.kernel_size != 7 else 0
 
-    def packed_weight(self, bf16: int = 0) -> Tensor:
+    def packed_weight(self, precision: int = 0) -> Tensor:
         """The slab-layout copy of the weight the kernel reads (one per compute mode), rebuilt when
         the parameter is modified in place (optimizer step, load_state_dict) or moved (`.to(device)`)."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
-        hit = self._packed.get(bf16)
+        hit = self._packed.get(precision)
         if hit is None or hit[0] != key:
-            hit = (key, ops.pack_conv_weight(w.detach().contiguous(), self.stride, bf16=bf16))
-            self._packed[bf16] = hit
+            hit = (key, ops.pack_conv_weight(w.detach().contiguous(), self.stride, precision=precision))
+            self._packed[precision] = hit
         return hit[1]
 
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
@@ -64,8 +64,8 @@ class Conv2d(nn.Module):
                             pixel_shuffle=pixel_shuffle, packed=self.packed_weight())
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
-                          pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._bf16()),
-                          bf16=self._bf16())
+                          pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._precision()),
+                          precision=self._precision())
 
 
 def conv1x1(in_ch, out_ch, stride=1):

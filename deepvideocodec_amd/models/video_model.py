@@ -491,23 +491,24 @@ class DMC(nn.Module):
         for them; call once before driving the model from several host threads / streams."""
         for m in self.modules():
             if isinstance(m, Conv2d):
-                m.packed_weight(m._bf16())
+                m.packed_weight(m._precision())
         if next(self.parameters()).is_cuda:
             torch.cuda.synchronize()
         return self
 
     def set_precision(self, precision: str = "fp32"):
-        """"fp32" (default): exact fp32 convolutions, the parity path.  "bf16": the 1x1 / 3x3
-        convolutions round their operands to bf16 and accumulate in fp32 (3-4x faster, results differ
-        from the fp32 path; encoder and decoder must use the same setting).  "bf16x2": operands split
-        into two bf16 parts (hi + lo, 16 mantissa bits), three bf16 matrix products per convolution
-        term.  Inference only: under autograd the convolutions always run in fp32."""
-        modes = {"fp32": 0, "bf16": 1, "bf16x2": 2}
-        if precision not in modes:
+        """"fp32" (default): exact fp32 convolutions, the parity path.  The other modes change how the
+        1x1 / 3x3 convolutions form their products (fp32 accumulation and fp32 tensors throughout; the
+        7x7 motion-estimation layers stay fp32; encoder and decoder must use the same setting):
+        "bf16": operands rounded to bf16 (3-4x faster convolutions, visibly different results);
+        "bf16x2": operands split into bf16 hi + lo parts (16 significant bits), three 16-bit matrix
+        products per term; "fp16x2": the same with fp16 parts (22 significant bits; operands must stay
+        below ~1.3e5 in magnitude).  Inference only: under autograd the convolutions run in fp32."""
+        if precision not in ops.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
         for m in self.modules():
             if isinstance(m, Conv2d):
-                m.compute_bf16 = modes[precision]
+                m.precision = ops.PRECISIONS[precision]
         return self
 
     def aux_loss(self):

@@ -61,21 +61,25 @@ def _ptr(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def pack_conv_weight(weight: Tensor, stride: int = 1, bf16: int = 0) -> Tensor:
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x2": 2, "fp16x2": 3}
+
+
+def pack_conv_weight(weight: Tensor, stride: int = 1, precision: int = 0) -> Tensor:
     """OIHW weight -> the slab layout dvc_conv2d reads (re-pack whenever the weight changes).
-    `bf16`: 0 = exact fp32; 1 = bf16-rounded operands; 2 = split bf16 hi + lo operands (1x1 / 3x3 only)."""
+    `precision` (PRECISIONS): 0 exact fp32; 1 bf16-rounded operands; 2 / 3 operands split into bf16 / fp16
+    hi + lo parts (1x1 / 3x3 only)."""
     if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32 and weight.dim() == 4):
         raise ValueError("pack_conv_weight: weight must be a contiguous fp32 OIHW GPU tensor")
     cout, cin, k, k2 = weight.shape
     if k != k2:
         raise ValueError("pack_conv_weight: square kernels only")
     lib = _lib.load()
-    bf16 = int(bf16)
-    if bf16:
-        n = check(lib.dvc_conv2d_bf16_packed_weight_floats(cout, cin, k, stride, bf16), "dvc_conv2d_bf16_packed_weight_floats")
+    precision = int(precision)
+    if precision:
+        n = check(lib.dvc_conv2d_reduced_packed_weight_floats(cout, cin, k, stride, precision), "dvc_conv2d_reduced_packed_weight_floats")
         packed = torch.empty(n, dtype=torch.float32, device=weight.device)
-        check(lib.dvc_conv2d_bf16_pack_weight(weight.data_ptr(), cout, cin, k, stride, bf16, packed.data_ptr(), _stream()),
-              "dvc_conv2d_bf16_pack_weight")
+        check(lib.dvc_conv2d_reduced_pack_weight(weight.data_ptr(), cout, cin, k, stride, precision, packed.data_ptr(), _stream()),
+              "dvc_conv2d_reduced_pack_weight")
         return packed
     n = check(lib.dvc_conv2d_packed_weight_floats(cout, cin, k, stride), "dvc_conv2d_packed_weight_floats")
     packed = torch.empty(n, dtype=torch.float32, device=weight.device)
@@ -88,9 +92,9 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
            in_slope: Optional[float] = None, out_slope: Optional[float] = None,
            residual: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
            residual2: Optional[Tensor] = None, pixel_shuffle: bool = False,
-           out: Optional[Tensor] = None, packed: Optional[Tensor] = None, bf16: int = 0) -> Tensor:
-    """See DvcConv2d in include/dvc_hip.h.  `bf16`: 1 = operands rounded to bf16, 2 = operands split into bf16 hi + lo parts; fp32
-    accumulation either way (`packed` must come from pack_conv_weight(..., bf16=) with the same value). `srcs` are concatenated along C; slopes of
+           out: Optional[Tensor] = None, packed: Optional[Tensor] = None, precision: int = 0) -> Tensor:
+    """See DvcConv2d in include/dvc_hip.h.  `precision`: see PRECISIONS; fp32 accumulation in every mode (`packed` must come from
+    pack_conv_weight(..., precision=) with the same value). `srcs` are concatenated along C; slopes of
     None mean "no activation", 0.0 means ReLU.  `weight` is the OIHW tensor (its shape
     describes the layer); `packed` its pack_conv_weight() image -- packed on the fly if
     not given (callers that reuse a weight should cache it)."""
@@ -122,9 +126,9 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
     p.n_src = len(srcs)
     p.batch, p.in_h, p.in_w = n, h, w
     if packed is None:
-        packed = pack_conv_weight(weight, stride, bf16=bf16)
+        packed = pack_conv_weight(weight, stride, precision=precision)
     p.weight_packed = packed.data_ptr()
-    p.compute_bf16 = int(bf16)
+    p.precision = int(precision)
     p.bias = _ptr(bias)
     p.out_channels = cout
     p.ksize = k

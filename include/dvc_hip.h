@@ -67,6 +67,12 @@ typedef struct DvcDst {
  * With pixel_shuffle, `out`, `residual` and `res_scale` are laid out for the
  * shuffled tensor (Cout/4 channels, 2H x 2W).
  */
+/* Operand arithmetic of dvc_conv2d.  FP32: exact fp32 products on v_mfma_f32_32x32x2_f32 (the parity path).
+ * BF16: operands rounded to bf16.  BF16X2 / FP16X2: each operand split into hi + lo 16-bit parts (16 / 22
+ * significant bits), a product = hi*hi + hi*lo + lo*hi on the 16-bit matrix pipe.  FP16X2 operands saturate
+ * beyond +-131008. */
+enum { DVC_PRECISION_FP32 = 0, DVC_PRECISION_BF16 = 1, DVC_PRECISION_BF16X2 = 2, DVC_PRECISION_FP16X2 = 3 };
+
 typedef struct DvcConv2d {
   DvcSrc src[DVC_MAX_SRC];
   int32_t n_src;
@@ -86,11 +92,9 @@ typedef struct DvcConv2d {
   const float* res_scale;          /* NULL or [batch][out channels after shuffle] */
   const float* residual2;          /* NULL or a second tensor in output layout (needs residual) */
   int64_t res2_batch_stride, res2_chan_stride;
-  int32_t compute_bf16;            /* 0: exact fp32 MFMA (weight_packed from dvc_conv2d_pack_weight);
-                                      1: operands rounded to bf16, fp32 accumulate; 2: operands split
-                                      into two bf16 parts (16 mantissa bits), three bf16 MFMAs per
-                                      product, fp32 accumulate (weight_packed from
-                                      dvc_conv2d_bf16_pack_weight with parts = 1 / 2; ksize 1 or 3) */
+  int32_t precision;               /* DVC_PRECISION_*: how the products are formed (fp32 accumulation and fp32
+                                      tensors in every mode); weight_packed must have been packed for the
+                                      same mode.  Modes other than FP32 cover ksize 1 and 3 */
   int32_t _pad;
 } DvcConv2d;
 
@@ -105,12 +109,13 @@ int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
 
-/* The same for the bf16 compute modes: slabs are [part][tap][8-channel octet 0/1][co][8 x bf16] per 16
- * input channels, parts = 1 (rounded) or 2 (hi + lo split); the size is returned in 4-byte units. */
-int64_t dvc_conv2d_bf16_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
-                                             int32_t parts);
-int dvc_conv2d_bf16_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
-                                int32_t stride, int32_t parts, float* packed, void* stream);
+/* The same for the reduced-operand modes (precision = DVC_PRECISION_BF16 / BF16X2 / FP16X2): slabs are
+ * [part][tap][8-channel octet 0/1][co][8 x 16-bit] per 16 input channels, one part (rounded operands) or two
+ * (hi + lo split); the size is returned in 4-byte units. */
+int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
+                                                int32_t precision);
+int dvc_conv2d_reduced_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
+                                   int32_t stride, int32_t precision, float* packed, void* stream);
 
 /* Backward bilinear warp, border clamp, flow in pixels (ch0 = x, ch1 = y):
  * layers.py:175-198 (`torch_warp` = grid_sample(bilinear, border, align_corners=True)). */

@@ -45,4 +45,6 @@ def gpu_net(seeded_sd):
     net.load_state_dict(seeded_sd)
     net = net.to("cuda:0").eval()
     net.update(force=True)
+    import os
+    net.set_precision(os.environ.get("DVC_TEST_PRECISION", "fp32"))
     return net

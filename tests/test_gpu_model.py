@@ -330,17 +330,22 @@ def test_bf16_precision_option(seeded_sd):
 
     bpp32, psnr32, rec32 = run()
     net.set_precision("bf16")
-    assert net.contextual_encoder.conv1._bf16() and not net.optic_flow.moduleBasic[0].conv1._bf16()
+    assert net.contextual_encoder.conv1._precision() and not net.optic_flow.moduleBasic[0].conv1._precision()
     bpp16, psnr16, rec16 = run()
     assert not torch.equal(rec16[0], rec32[0])                 # it really is a different arithmetic
     assert abs(bpp16 - bpp32) <= 0.03 * bpp32, (bpp16, bpp32)
     assert all(abs(a - b) <= 0.1 for a, b in zip(psnr16, psnr32)), (psnr16, psnr32)
     net.set_precision("bf16x2")                                 # split operands: ~2^-17 per product
-    assert net.contextual_encoder.conv1._bf16() == 2
+    assert net.contextual_encoder.conv1._precision() == 2
     bpp2, psnr2, rec2 = run()
     assert not torch.equal(rec2[0], rec32[0])
     assert abs(bpp2 - bpp32) <= 2e-3 * bpp32, (bpp2, bpp32)
     assert all(abs(a - b) <= 2e-3 for a, b in zip(psnr2, psnr32)), (psnr2, psnr32)
+    net.set_precision("fp16x2")                                 # fp16 parts: ~2^-21 per product
+    assert net.contextual_encoder.conv1._precision() == 3
+    bpp3, psnr3, rec3 = run()
+    assert abs(bpp3 - bpp32) <= 2e-4 * bpp32, (bpp3, bpp32)
+    assert all(abs(a - b) <= 2e-4 for a, b in zip(psnr3, psnr32)), (psnr3, psnr32)
     net.set_precision("fp32")
     bpp_again, _, rec_again = run()
     assert bpp_again == bpp32 and torch.equal(rec_again[1], rec32[1])

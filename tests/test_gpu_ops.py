@@ -383,18 +383,21 @@ def test_conv2d_bf16_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slop
         want = F.leaky_relu(want, out_slope)
     want = (F.pixel_shuffle(want, 2) if shuffle else want) + res
     got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), stride=stride, in_slope=in_slope, out_slope=out_slope,
-                     pixel_shuffle=shuffle, residual=dev(res), bf16=True)
+                     pixel_shuffle=shuffle, residual=dev(res), precision=1)
     close(got, want, rel=2e-5)
     with pytest.raises(Exception):
-        ops.conv2d(dev(torch.randn(1, 8, 16, 16)), dev(torch.randn(8, 8, 7, 7)), None, bf16=True)
+        ops.conv2d(dev(torch.randn(1, 8, 16, 16)), dev(torch.randn(8, 8, 7, 7)), None, precision=1)
 
 
+@pytest.mark.parametrize("mode", ["bf16x2", "fp16x2"])
 @pytest.mark.parametrize("k,stride,cins,cout,H,W,batch,in_slope,out_slope,shuffle", BF16_CASES)
-def test_conv2d_bf16_split_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle):
-    """The split mode: every operand is hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is
-    hi*hi + hi*lo + lo*hi, summed in fp32.  It must agree with that expression evaluated in fp64 to fp32
-    noise, and with the exact convolution to ~2^-16 per product."""
+def test_conv2d_split_modes(k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle, mode):
+    """The split modes: every operand is hi + lo with hi = half(v), lo = half(v - hi), half = bf16 or
+    (saturating) fp16; a product is hi*hi + hi*lo + lo*hi, summed in fp32.  The result must agree with that
+    expression evaluated in fp64 to fp32 noise, and with the exact convolution to ~2^-16 (bf16 parts) or
+    ~2^-21 (fp16 parts) per product."""
     from deepvideocodec_amd import ops
+    half = torch.bfloat16 if mode == "bf16x2" else torch.float16
     g = torch.Generator().manual_seed(k * 37 + cout + H)
     parts = [torch.randn(batch, c, H, W, generator=g) for c in cins]
     cin = sum(cins)
@@ -405,8 +408,8 @@ def test_conv2d_bf16_split_mode(k, stride, cins, cout, H, W, batch, in_slope, ou
         x = F.leaky_relu(x, in_slope)
 
     def split(t):
-        hi = t.bfloat16().float()
-        return hi.double(), (t - hi).bfloat16().double()
+        hi = t.to(half).float()
+        return hi.double(), (t - hi).to(half).double()
 
     xh, xl = split(x)
     wh, wl = split(w)
@@ -419,6 +422,25 @@ def test_conv2d_bf16_split_mode(k, stride, cins, cout, H, W, batch, in_slope, ou
         want, exact = F.pixel_shuffle(want, 2), F.pixel_shuffle(exact, 2)
     res = torch.randn(want.shape, generator=g)
     got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), stride=stride, in_slope=in_slope, out_slope=out_slope,
-                     pixel_shuffle=shuffle, residual=dev(res), bf16=2)
+                     pixel_shuffle=shuffle, residual=dev(res), precision=ops.PRECISIONS[mode])
     close(got, (want + res).float(), rel=2e-5)
-    assert (got.cpu().double() - (exact + res)).abs().max().item() < 2e-4
+    err = (got.cpu().double() - (exact + res)).abs().max().item()
+    assert err < (2e-4 if mode == "bf16x2" else 1.5e-5), err
+
+
+def test_conv2d_fp16_split_range():
+    """fp16 parts: operands far below the fp16 normal range keep an absolute accuracy of ~2^-25 (subnormal
+    lo parts are not flushed), and operands beyond +-65504 saturate instead of becoming infinite."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 20, 36, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17
+    for scale in (1e-3, 1.0, 300.0):
+        xs = x * scale
+        exact = F.conv2d(xs.double(), w.double(), None, padding=1)
+        got = ops.conv2d(dev(xs), dev(w), None, precision=ops.PRECISIONS["fp16x2"]).cpu().double()
+        assert (got - exact).abs().max().item() < 3e-6 * max(scale, 1e-2) * 4, scale
+    big = x.clone()
+    big[0, 0, 3, 3] = 5e5
+    got = ops.conv2d(dev(big), dev(w), None, precision=ops.PRECISIONS["fp16x2"])
+    assert torch.isfinite(got).all()

@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
-    ap.add_argument("--bf16", type=int, default=0, help="1: bf16-rounded operands, 2: split bf16 hi + lo operands (k 1/3 only)")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16 hi+lo, 3 fp16 hi+lo (k 1/3 only)")
     ap.add_argument("--wgrad", type=int, default=0, help="1: time the weight-gradient kernel of the shape instead")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
@@ -66,7 +66,7 @@ def main():
         x = torch.randn(args.batch, cin, h, w, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
-        bf = args.bf16 if k != 7 else 0
+        bf = args.precision if k != 7 else 0
         if args.wgrad:
             ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
             g = torch.randn(args.batch, cout, ho, wo, device="cuda")
@@ -85,14 +85,14 @@ def main():
             total_t += ms
             total_f += flops
             continue
-        packed = ops.pack_conv_weight(wt, s, bf16=bf)
-        out = ops.conv2d(x, wt, b, stride=s, packed=packed, bf16=bf)
+        packed = ops.pack_conv_weight(wt, s, precision=bf)
+        out = ops.conv2d(x, wt, b, stride=s, packed=packed, precision=bf)
         for _ in range(2):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, bf16=bf)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, bf16=bf)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
