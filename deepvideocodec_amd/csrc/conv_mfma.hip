@@ -67,6 +67,7 @@ struct ConvArgs {
   int in_act, out_act, ps;
   int tiles_x;
   int vec4;               // output / residual rows allow 16-byte accesses
+  int soff_ok;            // every source spans < 2 GiB per sample: a channel can be a 32-bit scalar offset
 };
 
 // input channels staged per K-chunk (even)
@@ -250,24 +251,58 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const bool in_act = a.in_act != 0;
   const float in_slope = a.in_slope;
 
+  const bool soff_ok = a.soff_ok != 0;
+
+  // One K-chunk of input, global -> registers.  Common case (the chunk lies inside one source and
+  // inside cin): one buffer descriptor per chunk on the source's sample, the channel as the scalar
+  // offset operand of the load (not part of the range check, which keeps working per plane through
+  // the per-lane offsets) -- a couple of scalar instructions per channel and no branches, so the
+  // loads can be scheduled between the MFMAs of the current chunk.  Otherwise (a chunk straddling two
+  // concatenated sources, or running past the last channel): one descriptor per channel.
   auto prefetch_input = [&](int c0) {
+    const int cl = c0 + CK - 1;
+    const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
+    const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
+    const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
+    // plane lookup over the concatenated sources as mask arithmetic (select chains on these scalars
+    // get turned into a private-memory lookup table by the compiler); the telescoping sums work
+    // because g2 implies g1 implies g0
+    const bool g0 = c0 >= e0, g1 = c0 >= e1, g2 = c0 >= e2;
+    const bool fast = soff_ok && cl < cin && (cl >= e0) == g0 && (cl >= e1) == g1 && (cl >= e2) == g2;
+    if (fast) {   // workgroup-uniform
+      const unsigned long long m0 = 0ull - (unsigned long long)g0, m1 = 0ull - (unsigned long long)g1;
+      const unsigned long long m2 = 0ull - (unsigned long long)g2;
+      const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
+      const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
+      const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+      const unsigned cs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)cs);
+      const unsigned soff0 = __builtin_amdgcn_readfirstlane((unsigned)(c0 - first) * cs4);
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        // the range check compares the per-lane offset with (records - scalar offset): records end
+        // with this channel's plane
+        const unsigned soff = soff0 + (unsigned)c * cs4;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, soff + plane_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < IN_PT; ++j)
+          rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const int ci = c0 + c;
-      // plane of channel ci over the concatenated sources, as mask arithmetic (select chains on
-      // these scalars get turned into a private-memory lookup table by the compiler); the
-      // telescoping sums work because g2 implies g1 implies g0
       const bool have = ci < cin;
-      const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
       unsigned long long pl;
-      if (single_src) {   // workgroup-uniform: the common case costs one multiply-add per channel
+      if (single_src) {   // workgroup-uniform
         pl = have ? b0 + 4ull * (unsigned long long)((long long)ci * cs0) : b0;
       } else {
         const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
         const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
         const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
-        const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
-        const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
         const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
         const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
         const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
@@ -657,9 +692,11 @@ int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   const int mt = a.cout > 32 ? 2 : 1;
   // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
   // workgroups per CU, so those stop at 8 rows
-  const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : 4);
+  // (the split-operand 3x3 kernels hold two parts of every operand: 64 channels x 16 rows would spill)
+  constexpr bool WIDE_OK = !(S == 2 && KS != 1) && !(BF >= 2 && KS == 3);
+  const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : (mt == 2 && !WIDE_OK) ? 2 : 4);
   if (mt == 2) {
-    if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 2, 4, false, BF>(a, batch, st); }
+    if (nt == 4) { if constexpr (WIDE_OK) return launch<KS, S, 2, 4, false, BF>(a, batch, st); }
     if (nt == 2) return launch<KS, S, 2, 2, false, BF>(a, batch, st);
     // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
     const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
@@ -798,6 +835,9 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
     a.vec4 = (a.ps ? a.wo % 2 == 0 : a.wo % 4 == 0) && al(a.out, a.obs, a.ocs) && (!a.res || al(a.res, a.rbs, a.rcs)) &&
              (!a.res2 || al(a.res2, a.r2bs, a.r2cs));
   }
+  a.soff_ok = 1;
+  for (int i = 0; i < p->n_src; ++i)
+    if (((long long)p->src[i].channels + 1) * p->src[i].chan_stride * 4 >= (1LL << 31)) a.soff_ok = 0;
   a.in_slope = p->in_act ? p->in_slope : 1.0f;    // leaky(v, 1) == v exactly
   a.out_slope = p->out_act ? p->out_slope : 1.0f;
   a.in_act = p->in_act ? 1 : 0;
