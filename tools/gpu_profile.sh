@@ -12,8 +12,8 @@ mkdir -p $O
 cd $R
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py > $O/bench.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_g1 -o bench_g1 -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 > $O/bench_g1.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --steps 1 --warmup 0 --gop 3 > $O/pmc_fetch.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --steps 1 --warmup 0 --gop 3 > $O/pmc_write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --alt-precision none --steps 1 --warmup 0 --gop 3 > $O/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --alt-precision none --steps 1 --warmup 0 --gop 3 > $O/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_sq -o sq -- python3 tools/conv_bench.py --shapes main,c128_64 --iters 5 > $O/pmc_sq.log 2>&1
 find $O -name '*.csv' | xargs ls -la
 # MFMA pipe occupancy of the dominant conv shapes: busy cycles of the matrix pipe over all SIMDs
