@@ -4,7 +4,7 @@ context / transform nets), same constructor defaults, attribute / parameter name
 method signatures and return structures.  The tensor work is done by the HIP kernels
 of libdvc_hip.so through `deepvideocodec_amd.ops`; torch only carries device memory.
 
-Differences from the reference that a caller can observe (all documented in DESIGN.md):
+Differences from the reference that a caller can observe:
   * a tensor on the CPU is rejected instead of silently taking a CPU path.
   * forward() / forward_inter() are differentiable when torch's grad mode is on (the training
     path: same forward kernels on the autograd tape, gradient kernels behind them); under
