@@ -471,29 +471,45 @@ __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
 }
 
 
-// gW[co][ci][tap] = sum over splits (ascending) of partial[split][tap][co][ci]
-// gB[co] = sum over splits (ascending) of bias_partial[split][co]  (indices past the weight's)
+// gW[co][ci][tap] = sum over splits of partial[split][tap][co][ci]; gB[co] = sum over splits of
+// bias_partial[split][co] (indices past the weight's).  A block handles 64 results; its four waves each
+// add every fourth split (independent loads in flight instead of one long dependent chain) and the four
+// sums are combined through LDS in a fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* gw, int nsplit, int taps,
                                                            int cout, int cin, int cout_pad, int cin_pad,
                                                            const float* bias_partial, float* gb) {
+  __shared__ float part[4][64];
   const long long total = (long long)cout * taps * cin;
   const long long sstride = (long long)taps * cout_pad * cin_pad;
   const long long total_all = total + (gb != nullptr ? cout : 0);
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_all; i += (long long)gridDim.x * 256) {
-    if (i >= total) {
-      const int co = (int)(i - total);
-      float s = 0.f;
-      for (int k = 0; k < nsplit; ++k) s += bias_partial[(long long)k * cout_pad + co];
-      gb[co] = s;
-      continue;
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  for (long long i0 = blockIdx.x * 64LL; i0 < total_all; i0 += (long long)gridDim.x * 64) {   // block-uniform
+    const long long i = i0 + lane;
+    const float* p = nullptr;
+    long long step = 0;
+    long long dst = -1;
+    if (i < total) {
+      const int ci = (int)(i % cin);
+      const long long q = i / cin;
+      const int tap = (int)(q % taps), co = (int)(q / taps);
+      p = partial + ((long long)tap * cout_pad + co) * cin_pad + ci;
+      step = sstride;
+      dst = ((long long)co * cin + ci) * taps + tap;
+    } else if (i < total_all) {
+      p = bias_partial + (i - total);
+      step = cout_pad;
     }
-    const int ci = (int)(i % cin);
-    const long long q = i / cin;
-    const int tap = (int)(q % taps), co = (int)(q / taps);
-    const float* p = partial + ((long long)tap * cout_pad + co) * cin_pad + ci;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[k * sstride];
-    gw[((long long)co * cin + ci) * taps + tap] = s;
+    if (p != nullptr)
+      for (int k = kg; k < nsplit; k += 4) s += p[k * step];
+    part[kg][lane] = s;
+    __syncthreads();
+    if (kg == 0 && p != nullptr) {
+      const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      if (dst >= 0) gw[dst] = v;
+      else gb[i - total] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -633,7 +649,7 @@ extern "C" int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch
   else rc = launch7(a, p, st);
   if (rc) return rc;
   const long long total = (long long)out_channels * cin * p.taps + out_channels;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, st, scratch, grad_weight,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dvc::stream_grid(total, 64)), dim3(256), 0, st, scratch, grad_weight,
                      p.nsplit, p.taps, out_channels, cin, p.cout_pad, p.cin_pad, a.bias_partial, grad_bias);
   return dvc::check_launch("wgrad_reduce_kernel");
 }
