@@ -174,55 +174,152 @@ __device__ __forceinline__ float linspace_pm1(int idx, int steps) {
 // zeroed by the caller; it is accumulated with float atomics (several output pixels may sample
 // the same source pixel).  gflow follows grid_sample's rule: no gradient through a coordinate
 // that was clipped to the border (position <= 0 or >= size - 1).
+//
+// A workgroup takes an 8 x 32 tile of output pixels.  The sampling positions and the four bilinear
+// weights of a pixel are the same for every channel, and the flow is smooth: the 2 x 2 neighbourhoods
+// of a tile fall into a small window of the source plane.  When that window fits the LDS tile (it
+// does unless the flow varies by more than ~7 pixels inside the tile), the channels go through LDS
+// four at a time: the source window is loaded with coalesced reads, the gradient is scattered with LDS
+// atomics, and the window is flushed with one global atomic per touched element -- instead of four
+// scattered global atomics and four scattered loads per pixel and channel.  Tiles whose window does
+// not fit take those directly.
+struct WarpTap {
+  int o_nw;            // offset of the north-west tap in the source plane
+  bool in_e, in_s;     // east / south taps exist
+  float ee, we, ss, ns;
+  float mx, my, sx, sy;
+  int ix, iy;
+};
+
+__device__ __forceinline__ WarpTap warp_tap(const Src& flow, int n, int pix, int x, int y, int h, int w) {
+  WarpTap t;
+  const float* fp = flow.p + n * flow.bs + pix;
+  const float u = fp[0], v = fp[flow.cs];
+  t.sx = (float)((w - 1.0) / 2.0);
+  t.sy = (float)((h - 1.0) / 2.0);
+  float gx = linspace_pm1(x, w) + u / t.sx;
+  float gy = linspace_pm1(y, h) + v / t.sy;
+  if (w == 1) gx = -1.0f + u / t.sx;
+  if (h == 1) gy = -1.0f + v / t.sy;
+  float fx = (gx + 1.0f) * t.sx, fy = (gy + 1.0f) * t.sy;
+  t.mx = (fx <= 0.f || fx >= (float)(w - 1)) ? 0.f : 1.f;
+  t.my = (fy <= 0.f || fy >= (float)(h - 1)) ? 0.f : 1.f;
+  fx = fminf((float)(w - 1), fmaxf(fx, 0.0f));
+  fy = fminf((float)(h - 1), fmaxf(fy, 0.0f));
+  const float xw = floorf(fx), yn = floorf(fy);
+  t.we = fx - xw;
+  t.ee = 1.0f - t.we;
+  t.ns = fy - yn;
+  t.ss = 1.0f - t.ns;
+  t.ix = (int)xw;
+  t.iy = (int)yn;
+  t.in_e = t.ix + 1 < w;
+  t.in_s = t.iy + 1 < h;
+  t.o_nw = t.iy * w + t.ix;
+  return t;
+}
+
+constexpr int WB_TH = 8, WB_TW = 32, WB_CH = 4, WB_WIN = 1280;   // window elements per channel (e.g. 24 x 48)
+
 __global__ __launch_bounds__(256) void flow_warp_backward_kernel(Src src, Src flow, Src gout, Dst gsrc, int want_gsrc,
-                                                                 Dst gflow, int want_gflow, int batch, int h, int w) {
-  const long long hw = (long long)h * w;
-  FOREACH(hw * batch) {
-    const int n = (int)(i / hw);
-    const int pix = (int)(i - n * hw);
-    const int y = pix / w, x = pix - y * w;
-    const float* fp = flow.p + n * flow.bs + pix;
-    const float u = fp[0], v = fp[flow.cs];
-    const float sx = (float)((w - 1.0) / 2.0), sy = (float)((h - 1.0) / 2.0);
-    float gx = linspace_pm1(x, w) + u / sx;
-    float gy = linspace_pm1(y, h) + v / sy;
-    if (w == 1) gx = -1.0f + u / sx;
-    if (h == 1) gy = -1.0f + v / sy;
-    float fx = (gx + 1.0f) * sx, fy = (gy + 1.0f) * sy;
-    const float mx = (fx <= 0.f || fx >= (float)(w - 1)) ? 0.f : 1.f;
-    const float my = (fy <= 0.f || fy >= (float)(h - 1)) ? 0.f : 1.f;
-    fx = fminf((float)(w - 1), fmaxf(fx, 0.0f));
-    fy = fminf((float)(h - 1), fmaxf(fy, 0.0f));
-    const float xw = floorf(fx), yn = floorf(fy);
-    const float we = fx - xw, ee = 1.0f - we, ns = fy - yn, ss = 1.0f - ns;
-    const int ix = (int)xw, iy = (int)yn;
-    const bool in_e = ix + 1 < w, in_s = iy + 1 < h;
-    const int o_nw = iy * w + ix, o_ne = o_nw + 1, o_sw = o_nw + w, o_se = o_nw + w + 1;
-    float gix = 0.f, giy = 0.f;
+                                                                 Dst gflow, int want_gflow, int h, int w) {
+  __shared__ float s_src[WB_CH][WB_WIN];
+  __shared__ float s_acc[WB_CH][WB_WIN];
+  __shared__ int s_box[4];   // min x, min y, max x, max y of the taps of the tile
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z;
+  const int x = blockIdx.x * WB_TW + (tid & 31), y = blockIdx.y * WB_TH + (tid >> 5);
+  const bool valid = x < w && y < h;
+  const int pix = valid ? y * w + x : 0;
+  if (tid == 0) {
+    s_box[0] = s_box[1] = 0x7fffffff;
+    s_box[2] = s_box[3] = -1;
+  }
+  __syncthreads();
+  WarpTap t = warp_tap(flow, n, pix, valid ? x : 0, valid ? y : 0, h, w);
+  if (valid) {
+    atomicMin(&s_box[0], t.ix);
+    atomicMin(&s_box[1], t.iy);
+    atomicMax(&s_box[2], t.ix + (t.in_e ? 1 : 0));
+    atomicMax(&s_box[3], t.iy + (t.in_s ? 1 : 0));
+  }
+  __syncthreads();
+  const int wx0 = s_box[0], wy0 = s_box[1];
+  const int ww = s_box[2] - wx0 + 1, wh = s_box[3] - wy0 + 1;
+  const int wsize = ww * wh;
+  float gix = 0.f, giy = 0.f;
+
+  if (wsize <= WB_WIN) {   // workgroup-uniform
+    const int l_nw = (t.iy - wy0) * ww + (t.ix - wx0);
+    for (int c0 = 0; c0 < gout.c; c0 += WB_CH) {
+      const int nch = min(WB_CH, gout.c - c0);
+      for (int idx = tid; idx < nch * wsize; idx += 256) {
+        const int k = idx / wsize, e = idx - k * wsize;
+        const int ey = e / ww, ex = e - ey * ww;
+        s_acc[k][e] = 0.f;
+        if (want_gflow) s_src[k][e] = src.p[n * src.bs + (c0 + k) * src.cs + (long long)(wy0 + ey) * w + wx0 + ex];
+      }
+      __syncthreads();
+      if (valid) {
+        for (int k = 0; k < nch; ++k) {
+          const float g = gout.p[n * gout.bs + (c0 + k) * gout.cs + pix];
+          if (want_gsrc) {
+            float* a = s_acc[k] + l_nw;
+            atomicAdd(a, g * (t.ss * t.ee));
+            if (t.in_e) atomicAdd(a + 1, g * (t.ss * t.we));
+            if (t.in_s) atomicAdd(a + ww, g * (t.ns * t.ee));
+            if (t.in_e && t.in_s) atomicAdd(a + ww + 1, g * (t.ns * t.we));
+          }
+          if (want_gflow) {
+            const float* sp = s_src[k] + l_nw;
+            const float nw = sp[0];
+            const float ne = t.in_e ? sp[1] : 0.f;
+            const float sw = t.in_s ? sp[ww] : 0.f;
+            const float se = (t.in_e && t.in_s) ? sp[ww + 1] : 0.f;
+            gix += g * ((ne - nw) * t.ss + (se - sw) * t.ns);
+            giy += g * ((sw - nw) * t.ee + (se - ne) * t.we);
+          }
+        }
+      }
+      __syncthreads();
+      if (want_gsrc) {
+        for (int idx = tid; idx < nch * wsize; idx += 256) {
+          const int k = idx / wsize, e = idx - k * wsize;
+          const float v = s_acc[k][e];
+          if (v != 0.f) {
+            const int ey = e / ww, ex = e - ey * ww;
+            atomicAdd(gsrc.p + n * gsrc.bs + (c0 + k) * gsrc.cs + (long long)(wy0 + ey) * w + wx0 + ex, v);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (valid) {
+    const int o_nw = t.o_nw, o_ne = o_nw + 1, o_sw = o_nw + w, o_se = o_nw + w + 1;
     for (int c = 0; c < gout.c; ++c) {
       const float g = gout.p[n * gout.bs + c * gout.cs + pix];
       if (want_gsrc) {
         float* gs = gsrc.p + n * gsrc.bs + c * gsrc.cs;
-        atomicAdd(gs + o_nw, g * (ss * ee));
-        if (in_e) atomicAdd(gs + o_ne, g * (ss * we));
-        if (in_s) atomicAdd(gs + o_sw, g * (ns * ee));
-        if (in_e && in_s) atomicAdd(gs + o_se, g * (ns * we));
+        atomicAdd(gs + o_nw, g * (t.ss * t.ee));
+        if (t.in_e) atomicAdd(gs + o_ne, g * (t.ss * t.we));
+        if (t.in_s) atomicAdd(gs + o_sw, g * (t.ns * t.ee));
+        if (t.in_e && t.in_s) atomicAdd(gs + o_se, g * (t.ns * t.we));
       }
       if (want_gflow) {
         const float* sp = src.p + n * src.bs + c * src.cs;
         const float nw = sp[o_nw];
-        const float ne = in_e ? sp[o_ne] : 0.f;
-        const float sw = in_s ? sp[o_sw] : 0.f;
-        const float se = (in_e && in_s) ? sp[o_se] : 0.f;
-        gix += g * ((ne - nw) * ss + (se - sw) * ns);
-        giy += g * ((sw - nw) * ee + (se - ne) * we);
+        const float ne = t.in_e ? sp[o_ne] : 0.f;
+        const float sw = t.in_s ? sp[o_sw] : 0.f;
+        const float se = (t.in_e && t.in_s) ? sp[o_se] : 0.f;
+        gix += g * ((ne - nw) * t.ss + (se - sw) * t.ns);
+        giy += g * ((sw - nw) * t.ee + (se - ne) * t.we);
       }
     }
-    if (want_gflow) {
-      float* gf = gflow.p + n * gflow.bs + pix;
-      gf[0] = (gix * sx * mx) / sx;
-      gf[gflow.cs] = (giy * sy * my) / sy;
-    }
+  }
+  if (want_gflow && valid) {
+    float* gf = gflow.p + n * gflow.bs + pix;
+    gf[0] = (gix * t.sx * t.mx) / t.sx;
+    gf[gflow.cs] = (giy * t.sy * t.my) / t.sy;
   }
 }
 
@@ -444,9 +541,10 @@ extern "C" int dvc_flow_warp_backward(const DvcSrc* src, const DvcSrc* flow, con
   DVC_REQUIRE(ws || wf, "dvc_flow_warp_backward: nothing to compute");
   if (ws) CHECK_DST(grad_src, plane, "dvc_flow_warp_backward(grad_src)");
   if (wf) CHECK_DST(grad_flow, plane, "dvc_flow_warp_backward(grad_flow)");
-  LAUNCH_1D(flow_warp_backward_kernel, (long long)batch * plane, stream, mk(src), mk(flow), mk(grad_out),
-            ws ? mk(grad_src) : Dst{nullptr, 0, 0}, ws ? 1 : 0, wf ? mk(grad_flow) : Dst{nullptr, 0, 0}, wf ? 1 : 0, batch,
-            h, w);
+  DVC_REQUIRE(batch <= 65535, "dvc_flow_warp_backward: batch too large");
+  hipLaunchKernelGGL(flow_warp_backward_kernel, dim3((w + WB_TW - 1) / WB_TW, (h + WB_TH - 1) / WB_TH, batch), dim3(256), 0,
+                     (hipStream_t)stream, mk(src), mk(flow), mk(grad_out), ws ? mk(grad_src) : Dst{nullptr, 0, 0},
+                     ws ? 1 : 0, wf ? mk(grad_flow) : Dst{nullptr, 0, 0}, wf ? 1 : 0, h, w);
   return dvc::check_launch("flow_warp_backward_kernel");
 }
 

@@ -142,6 +142,30 @@ def test_warp_gradients_match_grid_sample():
     close(dl.grad, cl.grad, rel=1e-3, what="grad flow")
 
 
+@pytest.mark.parametrize("channels,shift", [(6, (0.0, 0.0)), (3, (9.3, -5.6)), (9, (-70.0, 2.5))])
+def test_warp_gradients_smooth_flow(channels, shift):
+    """Smooth flows (the codec's case): the taps of an 8 x 32 tile fall into a small source window, which
+    takes the LDS path of the adjoint kernel; ragged sizes, channel counts off the group of four, a uniform
+    shift, and a shift that pushes everything against the border."""
+    from deepvideocodec_amd import autograd as A
+    g = torch.Generator().manual_seed(12 + channels)
+    H, W = 45, 83
+    feat = torch.randn(2, channels, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flow = torch.stack([2.0 * torch.sin(xx / 9.0 + yy / 14.0) + shift[0], 1.5 * torch.cos(xx / 11.0 - yy / 7.0) + shift[1]])
+    flow = flow.unsqueeze(0).repeat(2, 1, 1, 1) + 0.05 * torch.randn(2, 2, H, W, generator=g)
+    cf, cl = feat.clone().requires_grad_(), flow.clone().requires_grad_()
+    y_ref = O.flow_warp(cf, cl)
+    R = torch.randn(y_ref.shape, generator=g)
+    (y_ref * R).sum().backward()
+    df, dl = dev(feat).requires_grad_(), dev(flow).requires_grad_()
+    y = A.flow_warp(df, dl)
+    close(y, y_ref.detach(), what="forward")
+    (y * dev(R)).sum().backward()
+    close(df.grad, cf.grad, what="grad src")
+    close(dl.grad, cl.grad, rel=1e-3, what="grad flow")
+
+
 def test_pool_and_upsample_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(4)
