@@ -1,0 +1,39 @@
+// Launch arguments shared by the convolution kernels (conv_mfma.hip, conv_thin.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dvc_common.h"
+
+namespace dvc {
+
+struct ConvArgs {
+  DvcSrc src[DVC_MAX_SRC];
+  int n_src;
+  int cin, h, w;         // input
+  int cout, ho, wo;      // conv output (before shuffle)
+  const float* wpacked;  // [cout block][chunk][slab], see pack_weight_kernel
+  const float* bias;
+  float* out;
+  long long obs, ocs;
+  const float* res;
+  long long rbs, rcs;
+  const float* res_scale;
+  const float* res2;
+  long long r2bs, r2cs;
+  int c_final;           // channels of the stored tensor (cout or cout/4)
+  float in_slope, out_slope;
+  int in_act, out_act, ps;
+  int tiles_x;
+  int vec4;               // output / residual rows allow 16-byte accesses
+  int soff_ok;            // every source spans < 2 GiB per sample: a channel can be a 32-bit scalar offset
+};
+
+// fp32 packed weights (dvc_conv2d_pack_weight): input channels per K-chunk and floats per slab
+constexpr int conv_chunk_of(int ks, int s) { return ks == 7 ? 2 : ks == 1 ? 16 : (s == 2 ? 4 : 8); }
+constexpr int conv_slab_floats(int ks, int s, int cb) { return (conv_chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
+
+// conv_thin.hip: direct convolution for layers with at most 4 output channels
+bool thin_conv_applies(const ConvArgs& a, int ksize, int stride, int batch);
+int launch_thin_conv(const ConvArgs& a, int ksize, int batch, hipStream_t st);
+
+}  // namespace dvc

@@ -25,8 +25,11 @@
 #include <atomic>
 
 #include "dvc_common.h"
+#include "conv_args.h"
 
 namespace {
+
+using dvc::ConvArgs;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -48,34 +51,13 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-struct ConvArgs {
-  DvcSrc src[DVC_MAX_SRC];
-  int n_src;
-  int cin, h, w;         // input
-  int cout, ho, wo;      // conv output (before shuffle)
-  const float* wpacked;  // [cout block][chunk][slab], see pack_weight_kernel
-  const float* bias;
-  float* out;
-  long long obs, ocs;
-  const float* res;
-  long long rbs, rcs;
-  const float* res_scale;
-  const float* res2;
-  long long r2bs, r2cs;
-  int c_final;           // channels of the stored tensor (cout or cout/4)
-  float in_slope, out_slope;
-  int in_act, out_act, ps;
-  int tiles_x;
-  int vec4;               // output / residual rows allow 16-byte accesses
-  int soff_ok;            // every source spans < 2 GiB per sample: a channel can be a 32-bit scalar offset
-};
 
 // input channels staged per K-chunk (even)
-constexpr int chunk_of(int ks, int s) { return ks == 7 ? 2 : ks == 1 ? 16 : (s == 2 ? 4 : 8); }
+constexpr int chunk_of(int ks, int s) { return dvc::conv_chunk_of(ks, s); }
 constexpr int cout_block_of(int cout) { return cout > 32 ? 64 : 32; }
 // floats per packed weight slab: CK * k*k rows of CB output channels, padded to whole 1 KiB
 // pieces (one global_load_lds wave-instruction moves 64 lanes x 16 B)
-constexpr int slab_floats(int ks, int s, int cb) { return (chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
+constexpr int slab_floats(int ks, int s, int cb) { return dvc::conv_slab_floats(ks, s, cb); }
 
 // bf16 compute mode: K step of the MFMA is 16 input channels, held by a lane as 8 consecutive
 // channels (one "octet", 16 bytes).  A slab is [tap][octet 0/1][co][8 channels] in bf16, its size
@@ -862,6 +844,8 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
       default: return dispatch_tile<1, 2, 3>(a, p->batch, st);
     }
   }
+  // a handful of output channels would leave 28+ of the 32 MFMA rows idle: plain FMAs on the vector ALUs
+  if (dvc::thin_conv_applies(a, p->ksize, p->stride, p->batch)) return dvc::launch_thin_conv(a, p->ksize, p->batch, st);
   if (p->ksize == 3) return p->stride == 1 ? dispatch_tile<3, 1>(a, p->batch, st) : dispatch_tile<3, 2>(a, p->batch, st);
   if (p->ksize == 1) return p->stride == 1 ? dispatch_tile<1, 1>(a, p->batch, st) : dispatch_tile<1, 2>(a, p->batch, st);
   return dispatch_tile<7, 1>(a, p->batch, st);

@@ -444,3 +444,43 @@ def test_conv2d_fp16_split_range():
     big[0, 0, 3, 3] = 5e5
     got = ops.conv2d(dev(big), dev(w), None, precision=ops.PRECISIONS["fp16x2"])
     assert torch.isfinite(got).all()
+
+
+THIN_CASES = [
+    # k, cin, cout, H, W, batch, in_slope, out_slope, residuals
+    (7, 16, 2, 131, 517, 1, None, None, 1),      # SpyNet level output: + up-sampled flow (a channel slice)
+    (7, 16, 2, 64, 96, 6, 0.0, None, 0),         # batch supplies the tiles
+    (3, 64, 3, 136, 500, 1, None, None, 0),      # reconstruction layer
+    (3, 21, 4, 130, 515, 1, 0.1, 0.01, 2),
+    (3, 9, 1, 128, 512, 1, None, 0.2, 1),
+    (7, 5, 3, 129, 513, 1, 0.01, None, 0),       # fewer channels than one LDS chunk
+]
+
+
+@pytest.mark.parametrize("k,cin,cout,H,W,batch,in_slope,out_slope,nres", THIN_CASES)
+def test_conv2d_few_output_channels(k, cin, cout, H, W, batch, in_slope, out_slope, nres):
+    """Layers with at most 4 output channels and enough pixels run on the direct (vector-ALU) kernel:
+    same results as the convolution of the torch reference, fused activations and residuals included,
+    destination and residual given as channel slices of larger buffers."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(k * 131 + cin * 7 + cout)
+    x = torch.randn(batch, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    rbig = torch.randn(batch, cout + 6, H, W, generator=g)
+    r2 = torch.randn(batch, cout, H, W, generator=g)
+    xin = F.leaky_relu(x, in_slope) if in_slope is not None else x
+    want = F.conv2d(xin, w, b, padding=k // 2)
+    if out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    if nres >= 1:
+        want = want + rbig[:, 3:3 + cout]
+    if nres == 2:
+        want = want + r2
+    out_big = torch.zeros(batch, cout + 5, H, W, device="cuda:0")
+    rb = dev(rbig)
+    ops.conv2d(dev(x), dev(w), dev(b), in_slope=in_slope, out_slope=out_slope,
+               residual=rb[:, 3:3 + cout] if nres >= 1 else None, residual2=dev(r2) if nres == 2 else None,
+               out=out_big[:, 2:2 + cout])
+    close(out_big[:, 2:2 + cout], want)
+    assert float(out_big[:, :2].abs().max()) == 0.0 and float(out_big[:, 2 + cout:].abs().max()) == 0.0
