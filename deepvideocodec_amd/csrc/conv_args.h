@@ -32,6 +32,18 @@ struct ConvArgs {
 constexpr int conv_chunk_of(int ks, int s) { return ks == 7 ? 2 : ks == 1 ? 16 : (s == 2 ? 4 : 8); }
 constexpr int conv_slab_floats(int ks, int s, int cb) { return (conv_chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
 
+// conv_mfma_*.hip: the MFMA kernel variants, split over translation units by shape and precision
+// (ksize / stride select inside a unit; the caller has validated them)
+int conv_mfma_run_f32_k3s1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_f32_k3s2(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_f32_k1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_f32_k7(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_p1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_p2_k3(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_p2_k1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_p3_k3(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+int conv_mfma_run_p3_k1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
+
 // conv_thin.hip: direct convolution for layers with at most 4 output channels
 bool thin_conv_applies(const ConvArgs& a, int ksize, int stride, int batch);
 int launch_thin_conv(const ConvArgs& a, int ksize, int batch, hipStream_t st);

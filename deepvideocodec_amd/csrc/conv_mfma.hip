@@ -22,48 +22,9 @@
 // Fused around the MFMA loop: channel concat of up to 4 sources and LeakyReLU on
 // the input while staging; bias, LeakyReLU/ReLU, (scaled) residual adds and the
 // PixelShuffle(2) scatter in the epilogue.
-#include <atomic>
-
-#include "dvc_common.h"
-#include "conv_args.h"
+#include "conv_mfma_impl.h"
 
 namespace {
-
-using dvc::ConvArgs;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// 16-bit operand element of the reduced-operand modes: bf16 (modes 1, 2) or fp16 (mode 3).  The fp16
-// conversion saturates instead of overflowing to infinity.
-template <bool F16> struct Half16 { using T = __bf16; using V8 = bf16x8; };
-template <> struct Half16<true> { using T = _Float16; using V8 = f16x8; };
-template <bool F16>
-__device__ __forceinline__ typename Half16<F16>::T to_half16(float v) {
-  if constexpr (F16) return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-  else return (__bf16)v;
-}
-__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-
-// input channels staged per K-chunk (even)
-constexpr int chunk_of(int ks, int s) { return dvc::conv_chunk_of(ks, s); }
-constexpr int cout_block_of(int cout) { return cout > 32 ? 64 : 32; }
-// floats per packed weight slab: CK * k*k rows of CB output channels, padded to whole 1 KiB
-// pieces (one global_load_lds wave-instruction moves 64 lanes x 16 B)
-constexpr int slab_floats(int ks, int s, int cb) { return dvc::conv_slab_floats(ks, s, cb); }
-
-// bf16 compute mode: K step of the MFMA is 16 input channels, held by a lane as 8 consecutive
-// channels (one "octet", 16 bytes).  A slab is [tap][octet 0/1][co][8 channels] in bf16, its size
-// given here in 4-byte units like the fp32 slabs (padded to whole 1 KiB pieces).
-constexpr int BF_CK = 16;
-constexpr int slab_floats_bf16(int ks, int cb) { return (ks * ks * 2 * cb * 4 + 255) / 256 * 256; }
 
 template <bool F16>
 __global__ __launch_bounds__(256) void pack_weight_half_kernel(const float* w, typename Half16<F16>::T* packed, int cout, int cin, int ks,
@@ -102,592 +63,6 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
     if (row < ck * taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
     packed[i] = v;
   }
-}
-
-template <int MT, int NT>
-constexpr int min_waves_per_simd() { return 2; }
-
-// HALF: a 32-channel workgroup (MT = 1) working on one half of a 64-channel packed weight block,
-// used to double the number of workgroups of small launches whose weights are packed 64 wide.
-// BF: 0 = exact fp32 MFMA.  1 = operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-// 2 = every operand split into two bf16 parts, hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits), and
-// a product taken as hi*hi + hi*lo + lo*hi on the same MFMA: three bf16 MFMAs per 16 channels instead of
-// eight fp32 ones, relative error of a product <= ~2^-16.  With two parts the operand tiles are twice as
-// large and the LDS buffers are single (the next chunk is staged after the MFMA phase, not during it).
-// 3 = the same split with fp16 parts on v_mfma_f32_32x32x16_f16: hi = fp16(v), lo = fp16(v - hi) carry 22
-// significant bits (absolute floor 2^-25 from the fp16 subnormals, which the MFMA keeps), so a product is
-// within ~2^-21 of the fp32 one; operands saturate at +-65504 (hi) + 65504 (lo).
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
-struct Geo {
-  static_assert(!HALF || MT == 1, "half blocks are 32 channels");
-  static_assert(!BF || KS != 7, "the reduced-operand modes cover the 1x1 and 3x3 layers");
-  static constexpr int PARTS = BF >= 2 ? 2 : 1;
-  static constexpr bool F16 = BF == 3;
-  static constexpr int NBUF = PARTS == 2 ? 1 : 2;   // LDS buffers per operand
-  static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
-  static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
-  static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
-  static constexpr int IH = (TH - 1) * SL + KS;
-  static constexpr int IW = (TW - 1) * SL + KS;
-  static constexpr int CHS = IH * IW;            // floats per staged channel
-  static constexpr int TAPS = KS * KS;
-  static constexpr int KCH = CK * TAPS;          // k values per chunk
-  static constexpr int CBP = HALF ? 64 : CB;     // output channels per packed weight row
-  static constexpr int SLAB = BF ? PARTS * slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
-  // fp32: [channel][element]; bf16: [octet][element][8 channels] = 8 * CHS 4-byte units
-  static constexpr int IN_BUF = ((BF ? 8 * PARTS : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
-  static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
-  static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
-  static constexpr int STAGE_BYTES = NBUF * (IN_BUF + SLAB) * 4;
-  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4;   // four wave-private 32 x 36 transposition tiles
-  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-};
-
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
-__global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
-  using G = Geo<KS, S, MT, NT, HALF, BF>;
-  constexpr int CBP = G::CBP;
-  constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW;
-  constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
-
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NBUF = G::NBUF, PARTS = G::PARTS;
-  float* const w_s = lds;                   // [NBUF][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
-  float* const in_s = lds + NBUF * SLAB;    // [NBUF][IN_BUF]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
-  // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
-  // of them: the halo columns and rows shared by neighbouring tiles are then fetched into one L2
-  // once instead of into up to three.  (Any launch order gives correct results; this is locality.)
-  int tile;
-  {
-    const int nt = gridDim.x;
-    const int s = (int)((blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 7;   // XCD phase of this grid row
-    const int u = blockIdx.x + s, k = u & 7;
-    // launch slots of this row that land on XCDs < k: F(s + nt) - F(s), F(m) = (m / 8) k + min(m % 8, k)
-    const int m1 = s + nt;
-    const int before = (m1 >> 3) * k + min(m1 & 7, k) - min(s, k);
-    const int first_u = s + ((k - s) & 7);
-    tile = before + ((u - first_u) >> 3);
-  }
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int wblock = HALF ? (int)(blockIdx.y >> 1) : (int)blockIdx.y;   // packed weight block
-  const int cb0 = HALF ? wblock * 64 + (int)(blockIdx.y & 1) * 32 : wblock * CB;
-  if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
-  const int n = blockIdx.z;
-  const int nchunks = (a.cin + CK - 1) / CK;
-
-  // ---- per-thread staging descriptors (identical for every channel and chunk)
-  const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
-  const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
-  // byte offset of each staged element inside its channel plane; padding elements get an offset
-  // past every plane, for which the buffer load returns 0 (hardware range check) -- zero padding
-  // and the ragged last channel chunk cost no select instructions.
-  unsigned in_boff[IN_PT];
-#pragma unroll
-  for (int j = 0; j < IN_PT; ++j) {
-    const int i = tid + 256 * j;
-    const int iy = i / IW, ix = i - iy * IW;
-    const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
-    const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
-  }
-  const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
-  const float* wslabs = a.wpacked + (long long)wblock * nchunks * SLAB;
-
-  float rin[CK][IN_PT];
-
-  // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves
-  auto dma_weights = [&](int chunk, int buf) {
-    const float* src = wslabs + (long long)chunk * SLAB;
-    float* dst = w_s + buf * SLAB;
-#pragma unroll
-    for (int p = 0; p < (SLAB / 256 + 3) / 4; ++p) {
-      const int piece = wave + 4 * p;
-      if (piece < SLAB / 256)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
-            (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
-    }
-  };
-
-  // The (up to 4) concatenated sources, hoisted out of the kernel-argument segment once (plain
-  // scalars, not arrays: resolving a channel to its plane inside the K loop must cost neither
-  // dependent scalar loads nor scratch traffic).
-  // (unused sources have channels == 0 and a null pointer: they are never selected)
-  const float* const sp0 = a.src[0].ptr + (long long)n * a.src[0].batch_stride;
-  const float* const sp1 = a.src[1].ptr + (long long)n * a.src[1].batch_stride;
-  const float* const sp2 = a.src[2].ptr + (long long)n * a.src[2].batch_stride;
-  const float* const sp3 = a.src[3].ptr + (long long)n * a.src[3].batch_stride;
-  const long long cs0 = a.src[0].chan_stride, cs1 = a.src[1].chan_stride;
-  const long long cs2 = a.src[2].chan_stride, cs3 = a.src[3].chan_stride;
-  const int e0 = a.src[0].channels;   // first channel past source 0, 1, 2
-  const int e1 = e0 + a.src[1].channels;
-  const int e2 = e1 + a.src[2].channels;
-  const int cin = a.cin;
-  const bool single_src = a.n_src == 1;
-  const bool in_act = a.in_act != 0;
-  const float in_slope = a.in_slope;
-
-  const bool soff_ok = a.soff_ok != 0;
-
-  // One K-chunk of input, global -> registers.  Common case (the chunk lies inside one source and
-  // inside cin): one buffer descriptor per chunk on the source's sample, the channel as the scalar
-  // offset operand of the load (not part of the range check, which keeps working per plane through
-  // the per-lane offsets) -- a couple of scalar instructions per channel and no branches, so the
-  // loads can be scheduled between the MFMAs of the current chunk.  Otherwise (a chunk straddling two
-  // concatenated sources, or running past the last channel): one descriptor per channel.
-  auto prefetch_input = [&](int c0) {
-    const int cl = c0 + CK - 1;
-    const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
-    const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
-    const unsigned long long b2 = reinterpret_cast<unsigned long long>(sp2), b3 = reinterpret_cast<unsigned long long>(sp3);
-    // plane lookup over the concatenated sources as mask arithmetic (select chains on these scalars
-    // get turned into a private-memory lookup table by the compiler); the telescoping sums work
-    // because g2 implies g1 implies g0
-    const bool g0 = c0 >= e0, g1 = c0 >= e1, g2 = c0 >= e2;
-    const bool fast = soff_ok && cl < cin && (cl >= e0) == g0 && (cl >= e1) == g1 && (cl >= e2) == g2;
-    if (fast) {   // workgroup-uniform
-      const unsigned long long m0 = 0ull - (unsigned long long)g0, m1 = 0ull - (unsigned long long)g1;
-      const unsigned long long m2 = 0ull - (unsigned long long)g2;
-      const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
-      const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
-      const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-      const unsigned cs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)cs);
-      const unsigned soff0 = __builtin_amdgcn_readfirstlane((unsigned)(c0 - first) * cs4);
-#pragma unroll
-      for (int c = 0; c < CK; ++c) {
-        // the range check compares the per-lane offset with (records - scalar offset): records end
-        // with this channel's plane
-        const unsigned soff = soff0 + (unsigned)c * cs4;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, soff + plane_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < IN_PT; ++j)
-          rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
-      }
-      return;
-    }
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      const int ci = c0 + c;
-      const bool have = ci < cin;
-      unsigned long long pl;
-      if (single_src) {   // workgroup-uniform
-        pl = have ? b0 + 4ull * (unsigned long long)((long long)ci * cs0) : b0;
-      } else {
-        const unsigned long long m0 = 0ull - (unsigned long long)(ci >= e0);
-        const unsigned long long m1 = 0ull - (unsigned long long)(ci >= e1);
-        const unsigned long long m2 = 0ull - (unsigned long long)(ci >= e2);
-        const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
-        const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
-        const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
-        pl = have ? base + 4ull * (unsigned long long)((long long)(ci - first) * cs) : b0;
-      }
-      // wave-uniform buffer descriptor (made provably so for the compiler): base = plane,
-      // size = H*W*4 bytes, or 0 past the last channel so that every load returns 0
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pl);
-      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(pl >> 32));
-      const unsigned nbytes = __builtin_amdgcn_readfirstlane(have ? plane_bytes : 0u);
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
-#pragma unroll
-      for (int j = 0; j < IN_PT; ++j)
-        rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], 0, 0));
-    }
-  };
-
-  auto commit_input = [&](int buf) {
-    float* dst = in_s + buf * IN_BUF + tid;
-    if (in_act) {   // wave-uniform
-#pragma unroll
-      for (int c = 0; c < CK; ++c)
-#pragma unroll
-        for (int j = 0; j < IN_PT; ++j) rin[c][j] = dvc::leaky(rin[c][j], in_slope);
-    }
-    if constexpr (BF) {
-      // element i of the tile gets its 16 channels as two 16-byte octets: [octet][i][8 x bf16]
-      using V8 = typename Half16<G::F16>::V8;
-      V8* const d8 = reinterpret_cast<V8*>(in_s + buf * IN_BUF) + tid;
-#pragma unroll
-      for (int j = 0; j < IN_PT; ++j)
-        if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) {
-#pragma unroll
-          for (int o = 0; o < 2; ++o) {
-            V8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              hi[e] = to_half16<G::F16>(rin[8 * o + e][j]);
-              if constexpr (PARTS == 2) lo[e] = to_half16<G::F16>(rin[8 * o + e][j] - (float)hi[e]);
-            }
-            d8[o * CHS + 256 * j] = hi;
-            if constexpr (PARTS == 2) d8[(2 + o) * CHS + 256 * j] = lo;   // [part][octet][element]
-          }
-        }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CK; ++c) {
-#pragma unroll
-        for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
-          if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
-      }
-    }
-  };
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  const int b_lane = half * CHS + (wave * NT * SL) * IW + l32 * SL;
-  const int a_lane = (half * TAPS) * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
-  // bf16 mode, in 16-byte units: A [tap][octet][co], B [octet][element]
-  const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
-  const int b_lane8 = half * CHS + (wave * NT * SL) * IW + l32 * SL;
-
-  // ---- prologue: chunk 0 into buffer 0
-  dma_weights(0, 0);
-  prefetch_input(0);
-  commit_input(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int k = 0; k < nchunks; ++k) {
-    const int cur = NBUF == 2 ? (k & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
-    if (k + 1 < nchunks) {   // chunk k+1 in flight during the MFMA phase
-      if (NBUF == 2) dma_weights(k + 1, nxt);
-      prefetch_input((k + 1) * CK);
-    }
-    if constexpr (BF) {
-      using V8 = typename Half16<G::F16>::V8;
-      const V8* bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
-      const V8* abase = reinterpret_cast<const V8*>(w_s + cur * SLAB) + a_lane8;
-      if constexpr (PARTS == 1) {
-        V8 av[2][MT], bv[2][NT];
-        auto fetch = [&](int tap, int slot) {
-          const int ky = tap / KS, kx = tap - ky * KS;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[tap * 2 * CBP + mt * 32];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[(nt * SL + ky) * IW + kx];
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          if (t + 1 < TAPS) fetch(t + 1, (t + 1) & 1);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = mfma16(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt]);
-        }
-      } else {
-        // split operands: A parts [part][tap][octet][co], B parts [part][octet][element]; the small
-        // cross terms are accumulated before the leading one
-        constexpr int APART = TAPS * 2 * CBP, BPART = 2 * CHS;
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          const int ky = t / KS, kx = t - ky * KS;
-          V8 ah[MT], al[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            ah[mt] = abase[t * 2 * CBP + mt * 32];
-            al[mt] = abase[APART + t * 2 * CBP + mt * 32];
-          }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const V8 bh = bbase[(nt * SL + ky) * IW + kx];
-            const V8 bl = bbase[BPART + (nt * SL + ky) * IW + kx];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
-              acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
-              acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
-            }
-          }
-        }
-      }
-    } else {
-      const float* bbase = in_s + cur * IN_BUF + b_lane;
-      const float* abase = w_s + cur * SLAB + a_lane;
-      constexpr int T = (CK / 2) * TAPS;
-      float av[2][MT], bv[2][NT];
-      auto fetch = [&](int t, int slot) {
-        const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
-  #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CBP + mt * 32];
-  #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
-      };
-      fetch(0, 0);
-  #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
-  #ifndef DVC_NO_SCHED_PIN
-        __builtin_amdgcn_sched_barrier(0);          // keep those LDS reads ahead of this tap's MFMAs
-  #endif
-  #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-  #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
-  #ifndef DVC_NO_SCHED_PIN
-        __builtin_amdgcn_sched_barrier(0);
-  #endif
-      }
-    }
-    if (NBUF == 1) {   // single buffers: everyone must be done reading before the next chunk lands
-      __syncthreads();
-      if (k + 1 < nchunks) dma_weights(k + 1, 0);
-    }
-    if (k + 1 < nchunks) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
-    __syncthreads();
-  }
-
-  // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
-  // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
-  // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
-  // 128 stores of a lane cost no 64-bit vector address arithmetic.
-  const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
-  float* const out_n = a.out + (long long)n * a.obs;
-  const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
-  const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
-
-  if (a.vec4) {
-    // Fast path (everything 16-byte aligned).  Store instructions, not bytes, are what the epilogue
-    // pays for, so each 32 channel x 32 pixel accumulator tile is turned through a wave-private LDS
-    // tile ([channel][pixel], row stride RS) and leaves as 16-byte stores: 4 per lane instead of 16.
-    // All waves are past the K loop's last barrier, so the staging buffers are free; a wave's LDS
-    // instructions execute in order, so its reads see its own writes without a barrier.
-    constexpr int RS = 36;
-    static_assert(G::LDS_BYTES >= 4 * 32 * RS * 4, "epilogue tiles do not fit the staging buffers");
-    float* const tl = lds + wave * (32 * RS);
-    const int sub = lane >> 3, px4 = 4 * (lane & 7);       // plain: 8 lanes x 16 B per channel row
-    const int row = lane >> 4, px2 = 2 * (lane & 15);      // shuffle: 16 lanes x 16 B per output row
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int cu0 = cb0 + mt * 32;
-      float bias_r[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int oy = oy0 + wave * NT + nt;
-        if (oy >= a.ho) continue;   // wave-uniform
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = dvc::leaky(acc[mt][nt][r] + bias_r[r], a.out_slope);
-        if (!a.ps) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ch = cu0 + 8 * q + sub;
-            float4 v = *reinterpret_cast<const float4*>(tl + (8 * q + sub) * RS + px4);
-            if (ch < a.cout && ox0 + px4 < a.wo) {
-              const long long pix = (long long)oy * a.wo + ox0 + px4;
-              if (has_res) {
-                const float4 t = *reinterpret_cast<const float4*>(res_n + ch * a.rcs + pix);
-                if (has_scale) {
-                  const float sc = a.res_scale[n * a.c_final + ch];
-                  // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
-                  v.x = __fadd_rn(v.x, __fmul_rn(t.x, sc)); v.y = __fadd_rn(v.y, __fmul_rn(t.y, sc));
-                  v.z = __fadd_rn(v.z, __fmul_rn(t.z, sc)); v.w = __fadd_rn(v.w, __fmul_rn(t.w, sc));
-                } else {
-                  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
-                if (has_res2) {
-                  const float4 u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix);
-                  v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-              }
-              *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix) = v;
-            }
-          }
-        } else {
-          // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)): an output
-          // row interleaves two adjacent conv channels; a lane takes 2 pixels of both = 4 outputs
-          const long long wo2 = 2LL * a.wo;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int rr = 4 * q + row;                  // output row of the tile: (channel, dy)
-            const int c2l = rr >> 1, dy = rr & 1, chl = 4 * c2l + 2 * dy;
-            const int c2 = (cu0 >> 2) + c2l;
-            const float2 e = *reinterpret_cast<const float2*>(tl + chl * RS + px2);
-            const float2 o = *reinterpret_cast<const float2*>(tl + (chl + 1) * RS + px2);
-            float4 v = make_float4(e.x, o.x, e.y, o.y);
-            if (cu0 + chl < a.cout && ox0 + px2 < a.wo) {
-              const long long pix = (2LL * oy + dy) * wo2 + 2 * (ox0 + px2);
-              if (has_res) {
-                const float4 t = *reinterpret_cast<const float4*>(res_n + c2 * a.rcs + pix);
-                if (has_scale) {
-                  const float sc = a.res_scale[n * a.c_final + c2];
-                  // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
-                  v.x = __fadd_rn(v.x, __fmul_rn(t.x, sc)); v.y = __fadd_rn(v.y, __fmul_rn(t.y, sc));
-                  v.z = __fadd_rn(v.z, __fmul_rn(t.z, sc)); v.w = __fadd_rn(v.w, __fmul_rn(t.w, sc));
-                } else {
-                  v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
-                if (has_res2) {
-                  const float4 u = *reinterpret_cast<const float4*>(res2_n + c2 * a.r2cs + pix);
-                  v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-              }
-              *reinterpret_cast<float4*>(out_n + c2 * a.ocs + pix) = v;
-            }
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  // General path: one 4-byte store per accumulator register.
-  const int ox = ox0 + l32;
-  if (ox >= a.wo) return;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int cu0 = cb0 + mt * 32;   // wave-uniform first channel of the tile
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int oy = oy0 + wave * NT + nt;
-      if (oy >= a.ho) continue;
-      float rv[16], rv2[16];
-      if (!a.ps) {
-        const unsigned pix = (unsigned)(oy * a.wo + ox);
-        const unsigned o_lane = 4u * half * (unsigned)a.ocs + pix;
-        const unsigned r_lane = 4u * half * (unsigned)a.rcs + pix;
-        const unsigned r2_lane = 4u * half * (unsigned)a.r2cs + pix;
-        if (has_res) {   // issue all residual loads of the tile before using any
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cu = cu0 + (r & 3) + 8 * (r >> 2);
-            const bool ok = cu + 4 * half < a.cout;
-            // channels past Cout do not exist in the residual: such registers read channel 0, offset 0
-            const int cu_ld = cu < a.cout ? cu : 0;   // wave-uniform
-            rv[r] = (res_n + (long long)cu_ld * a.rcs)[ok ? r_lane : 0u];
-            if (has_scale) rv[r] = __fmul_rn(rv[r], a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)]);
-            rv2[r] = has_res2 ? (res2_n + (long long)cu_ld * a.r2cs)[ok ? r2_lane : 0u] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cu = cu0 + (r & 3) + 8 * (r >> 2);
-          if (cu + 4 * half >= a.cout) continue;
-          float v = acc[mt][nt][r] + bias_r[r];
-          v = dvc::leaky(v, a.out_slope);   // slope 1 when the layer has no output activation
-          if (has_res) {
-            v = __fadd_rn(v, rv[r]);
-            if (has_res2) v = __fadd_rn(v, rv2[r]);
-          }
-          (out_n + (long long)cu * a.ocs)[o_lane] = v;
-        }
-      } else {
-        // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); registers
-        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.  With
-        // co = cu + 4 half: shuffled channel (cu>>2) + half, row parity (cu>>1)&1.
-        const unsigned wo2 = 2u * (unsigned)a.wo;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int cu = cu0 + (r & 3) + 8 * (r >> 2);   // even
-          const bool ok = cu + 4 * half < a.cout;
-          const int c2u = cu >> 2, dy = (cu >> 1) & 1;
-          const unsigned pix = (unsigned)(2 * oy + dy) * wo2 + 2u * (unsigned)ox;
-          float v0 = acc[mt][nt][r] + bias_r[r], v1 = acc[mt][nt][r + 1] + bias_r[r + 1];
-          v0 = dvc::leaky(v0, a.out_slope);
-          v1 = dvc::leaky(v1, a.out_slope);
-          if (has_res && ok) {
-            const float2 t = *reinterpret_cast<const float2*>(res_n + (long long)c2u * a.rcs + (half * (unsigned)a.rcs + pix));
-            const float sc = has_scale ? a.res_scale[n * a.c_final + c2u + half] : 1.f;
-            v0 = __fadd_rn(v0, has_scale ? __fmul_rn(t.x, sc) : t.x);
-            v1 = __fadd_rn(v1, has_scale ? __fmul_rn(t.y, sc) : t.y);
-            if (has_res2) {
-              const float2 u = *reinterpret_cast<const float2*>(res2_n + (long long)c2u * a.r2cs + (half * (unsigned)a.r2cs + pix));
-              v0 += u.x;
-              v1 += u.y;
-            }
-          }
-          if (ok)
-            *reinterpret_cast<float2*>(out_n + (long long)c2u * a.ocs + (half * (unsigned)a.ocs + pix)) = make_float2(v0, v1);
-        }
-      }
-    }
-  }
-}
-
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
-int launch(const ConvArgs& a, int batch, hipStream_t st) {
-  using G = Geo<KS, S, MT, NT, HALF, BF>;
-  // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
-  // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
-  static std::atomic<unsigned long long> attr_done{0};
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
-  const unsigned long long device_bit = 1ull << device;
-  if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) {
-      dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
-      return DVC_EHIP;
-    }
-    attr_done.fetch_or(device_bit, std::memory_order_release);
-  }
-  ConvArgs b = a;
-  const int tiles_y = (a.ho + G::TH - 1) / G::TH;
-  b.tiles_x = (a.wo + G::TW - 1) / G::TW;
-  dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>), grid, dim3(256), G::LDS_BYTES, st, b);
-  return dvc::check_launch("conv_mfma_f32_kernel");
-}
-
-// Rows of 32 pixels per wave: the largest of max_nt / ... / 1 that still yields >= 2 workgroups per CU.
-inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
-  const long long cblocks = (a.cout + 32 * mt - 1) / (32 * mt);
-  const long long tx = (a.wo + 31) / 32;
-  for (int nt = max_nt; nt > 1; nt >>= 1) {
-    const long long blocks = (long long)((a.ho + 4 * nt - 1) / (4 * nt)) * tx * cblocks * batch;
-    if (blocks >= 480) return nt;   // (within a few percent of two workgroups per CU counts)
-  }
-  return 1;
-}
-
-template <int KS, int S, int BF = 0>
-int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
-  const int mt = a.cout > 32 ? 2 : 1;
-  // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
-  // workgroups per CU, so those stop at 8 rows
-  // (the split-operand 3x3 kernels hold two parts of every operand: 64 channels x 16 rows would spill)
-  constexpr bool WIDE_OK = !(S == 2 && KS != 1) && !(BF >= 2 && KS == 3);
-  const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : (mt == 2 && !WIDE_OK) ? 2 : 4);
-  if (mt == 2) {
-    if (nt == 4) { if constexpr (WIDE_OK) return launch<KS, S, 2, 4, false, BF>(a, batch, st); }
-    if (nt == 2) return launch<KS, S, 2, 2, false, BF>(a, batch, st);
-    // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
-    const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
-    if (blocks < 384) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
-    return launch<KS, S, 2, 1, false, BF>(a, batch, st);
-  }
-  if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4, false, BF>(a, batch, st); }
-  if (nt == 2) return launch<KS, S, 1, 2, false, BF>(a, batch, st);
-  return launch<KS, S, 1, 1, false, BF>(a, batch, st);
 }
 
 int check_geometry(int cout, int cin, int ks, int stride, const char* who) {
@@ -828,25 +203,17 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   if (p->precision != DVC_PRECISION_FP32) {
     DVC_REQUIRE(p->ksize != 7 && p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,
                 "dvc_conv2d: precision %d unknown, or a reduced-operand mode with ksize 7", p->precision);
-    const int key = p->precision * 100 + p->ksize * 10 + p->stride;
-    switch (key) {
-      case 131: return dispatch_tile<3, 1, 1>(a, p->batch, st);
-      case 132: return dispatch_tile<3, 2, 1>(a, p->batch, st);
-      case 111: return dispatch_tile<1, 1, 1>(a, p->batch, st);
-      case 112: return dispatch_tile<1, 2, 1>(a, p->batch, st);
-      case 231: return dispatch_tile<3, 1, 2>(a, p->batch, st);
-      case 232: return dispatch_tile<3, 2, 2>(a, p->batch, st);
-      case 211: return dispatch_tile<1, 1, 2>(a, p->batch, st);
-      case 212: return dispatch_tile<1, 2, 2>(a, p->batch, st);
-      case 331: return dispatch_tile<3, 1, 3>(a, p->batch, st);
-      case 332: return dispatch_tile<3, 2, 3>(a, p->batch, st);
-      case 311: return dispatch_tile<1, 1, 3>(a, p->batch, st);
-      default: return dispatch_tile<1, 2, 3>(a, p->batch, st);
-    }
+    if (p->precision == DVC_PRECISION_BF16) return dvc::conv_mfma_run_p1(a, p->ksize, p->stride, p->batch, st);
+    if (p->precision == DVC_PRECISION_BF16X2)
+      return p->ksize == 3 ? dvc::conv_mfma_run_p2_k3(a, 3, p->stride, p->batch, st)
+                           : dvc::conv_mfma_run_p2_k1(a, 1, p->stride, p->batch, st);
+    return p->ksize == 3 ? dvc::conv_mfma_run_p3_k3(a, 3, p->stride, p->batch, st)
+                         : dvc::conv_mfma_run_p3_k1(a, 1, p->stride, p->batch, st);
   }
   // a handful of output channels would leave 28+ of the 32 MFMA rows idle: plain FMAs on the vector ALUs
   if (dvc::thin_conv_applies(a, p->ksize, p->stride, p->batch)) return dvc::launch_thin_conv(a, p->ksize, p->batch, st);
-  if (p->ksize == 3) return p->stride == 1 ? dispatch_tile<3, 1>(a, p->batch, st) : dispatch_tile<3, 2>(a, p->batch, st);
-  if (p->ksize == 1) return p->stride == 1 ? dispatch_tile<1, 1>(a, p->batch, st) : dispatch_tile<1, 2>(a, p->batch, st);
-  return dispatch_tile<7, 1>(a, p->batch, st);
+  if (p->ksize == 3)
+    return p->stride == 1 ? dvc::conv_mfma_run_f32_k3s1(a, 3, 1, p->batch, st) : dvc::conv_mfma_run_f32_k3s2(a, 3, 2, p->batch, st);
+  if (p->ksize == 1) return dvc::conv_mfma_run_f32_k1(a, 1, p->stride, p->batch, st);
+  return dvc::conv_mfma_run_f32_k7(a, 7, 1, p->batch, st);
 }
