@@ -108,6 +108,104 @@ __global__ __launch_bounds__(256) void scale_planes_kernel(Src x, const float* s
   }
 }
 
+// ------------------------------------------------------------------ 16-byte variants
+// The element-wise kernels above move 4 bytes per lane and pay a 64-bit division per element; when every
+// plane is a multiple of 4 floats and all pointers / strides are 16-byte aligned the same work runs on
+// float4 units with 32-bit index arithmetic (plane4 = H*W/4 units per plane).  Selected on the host.
+__device__ __forceinline__ const float4* plane4_of(const Src& s, unsigned n, unsigned c) {
+  return reinterpret_cast<const float4*>(s.p + (long long)n * s.bs + (long long)c * s.cs);
+}
+__device__ __forceinline__ float4* plane4_of(const Dst& d, unsigned n, unsigned c) {
+  return reinterpret_cast<float4*>(d.p + (long long)n * d.bs + (long long)c * d.cs);
+}
+#define FOREACH4(total_expr)                                                  \
+  const unsigned total_ = (total_expr);                                       \
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total_; i += gridDim.x * 256u)
+
+__global__ __launch_bounds__(256) void act_grad4_kernel(Src g, Src t, int has_t, float slope, float4* out, unsigned chans,
+                                                        unsigned plane4, unsigned total) {
+  FOREACH4(total) {
+    const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
+    float4 v = plane4_of(g, n, c)[p4];
+    if (has_t) {
+      const float4 a = plane4_of(t, n, c)[p4];
+      v.x = a.x > 0.f ? v.x : v.x * slope; v.y = a.y > 0.f ? v.y : v.y * slope;
+      v.z = a.z > 0.f ? v.z : v.z * slope; v.w = a.w > 0.f ? v.w : v.w * slope;
+    }
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_act_grad4_kernel(Src g, Src x, Dst out, float slope, unsigned chans,
+                                                            unsigned plane4, unsigned total) {
+  FOREACH4(total) {
+    const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
+    float4 v = plane4_of(g, n, c)[p4];
+    const float4 a = plane4_of(x, n, c)[p4];
+    v.x = a.x > 0.f ? v.x : v.x * slope; v.y = a.y > 0.f ? v.y : v.y * slope;
+    v.z = a.z > 0.f ? v.z : v.z * slope; v.w = a.w > 0.f ? v.w : v.w * slope;
+    plane4_of(out, n, c)[p4] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_scaled4_kernel(Src a, Src b, const float* scale, Src c2, int has_c2, Dst out,
+                                                          unsigned chans, unsigned plane4, unsigned total) {
+  FOREACH4(total) {
+    const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
+    float4 bv = plane4_of(b, n, c)[p4];
+    if (scale != nullptr) {
+      const float sc = scale[q];
+      bv.x = __fmul_rn(bv.x, sc); bv.y = __fmul_rn(bv.y, sc); bv.z = __fmul_rn(bv.z, sc); bv.w = __fmul_rn(bv.w, sc);
+    }
+    const float4 av = plane4_of(a, n, c)[p4];
+    float4 v = make_float4(__fadd_rn(av.x, bv.x), __fadd_rn(av.y, bv.y), __fadd_rn(av.z, bv.z), __fadd_rn(av.w, bv.w));
+    if (has_c2) {
+      const float4 cv = plane4_of(c2, n, c)[p4];
+      v.x = __fadd_rn(v.x, cv.x); v.y = __fadd_rn(v.y, cv.y); v.z = __fadd_rn(v.z, cv.z); v.w = __fadd_rn(v.w, cv.w);
+    }
+    plane4_of(out, n, c)[p4] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_planes4_kernel(Src x, const float* scale, Dst out, unsigned chans,
+                                                            unsigned plane4, unsigned total) {
+  FOREACH4(total) {
+    const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
+    float4 v = plane4_of(x, n, c)[p4];
+    const float sc = scale[q];
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    plane4_of(out, n, c)[p4] = v;
+  }
+}
+
+// zero insertion, one float4 of the output row per lane: (s0, 0, s1, 0) on even rows, zeros on odd rows
+// (needs W % 4 == 0 and 2 w == W, 2 h == H; the source is read as float2)
+__global__ __launch_bounds__(256) void zero_upsample2_4_kernel(Src src, Dst out, unsigned chans, unsigned w, unsigned H,
+                                                               unsigned W4, unsigned total) {
+  FOREACH4(total) {
+    const unsigned x4 = i % W4;
+    unsigned q = i / W4;
+    const unsigned y = q % H;
+    q /= H;
+    const unsigned c = q % chans, n = q / chans;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(y & 1)) {
+      const float2 s2 = *reinterpret_cast<const float2*>(src.p + (long long)n * src.bs + (long long)c * src.cs +
+                                                         (long long)(y >> 1) * w + 2 * x4);
+      v.x = s2.x;
+      v.z = s2.y;
+    }
+    plane4_of(out, n, c)[(unsigned long long)y * W4 + x4] = v;
+  }
+}
+
+// host side: can this operand be addressed in float4 units?
+inline bool al16(const void* p, long long bs, long long cs) {
+  return reinterpret_cast<uintptr_t>(p) % 16 == 0 && bs % 4 == 0 && cs % 4 == 0;
+}
+inline bool al16(const DvcSrc* s) { return s == nullptr || al16(s->ptr, s->batch_stride, s->chan_stride); }
+inline bool al16(const DvcDst* d) { return al16(d->ptr, d->batch_stride, d->chan_stride); }
+
 // ------------------------------------------------------------------ plane dot products
 constexpr int SLICES = 64;
 
@@ -445,6 +543,12 @@ extern "C" int dvc_act_grad(const DvcSrc* grad, const DvcSrc* act_out, float slo
     DVC_REQUIRE(act_out->channels == stored_c, "dvc_act_grad: act_out channel mismatch");
   }
   const long long total = (long long)batch * channels * ho * wo;
+  if (!pixel_shuffle && plane % 4 == 0 && total / 4 < (1LL << 31) && al16(grad) && al16(act_out) &&
+      reinterpret_cast<uintptr_t>(grad_pre) % 16 == 0) {
+    LAUNCH_1D(act_grad4_kernel, total / 4, stream, mk(grad), act_out ? mk(act_out) : Src{nullptr, 0, 0, 0}, act_out ? 1 : 0,
+              slope, reinterpret_cast<float4*>(grad_pre), (unsigned)channels, (unsigned)(plane / 4), (unsigned)(total / 4));
+    return dvc::check_launch("act_grad4_kernel");
+  }
   LAUNCH_1D(act_grad_kernel, total, stream, mk(grad), act_out ? mk(act_out) : Src{nullptr, 0, 0, 0}, act_out ? 1 : 0,
             slope, pixel_shuffle ? 1 : 0, grad_pre, batch, channels, ho, wo);
   return dvc::check_launch("act_grad_kernel");
@@ -458,6 +562,14 @@ extern "C" int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope
   CHECK_SRC(x, plane, "dvc_mul_act_grad(x)");
   DVC_REQUIRE(x->channels == grad->channels, "dvc_mul_act_grad: channel mismatch");
   CHECK_DST(out, plane, "dvc_mul_act_grad");
+  {
+    const long long total = (long long)batch * grad->channels * plane;
+    if (plane % 4 == 0 && total / 4 < (1LL << 31) && al16(grad) && al16(x) && al16(out)) {
+      LAUNCH_1D(mul_act_grad4_kernel, total / 4, stream, mk(grad), mk(x), mk(out), slope, (unsigned)grad->channels,
+                (unsigned)(plane / 4), (unsigned)(total / 4));
+      return dvc::check_launch("mul_act_grad4_kernel");
+    }
+  }
   LAUNCH_1D(mul_act_grad_kernel, (long long)batch * grad->channels * plane, stream, mk(grad), mk(x), mk(out), slope,
             batch, h, w);
   return dvc::check_launch("mul_act_grad_kernel");
@@ -468,6 +580,15 @@ extern "C" int dvc_zero_upsample2(const DvcSrc* src, const DvcDst* out, int32_t 
   DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && out_h >= 2 * h - 1 && out_w >= 2 * w - 1, "dvc_zero_upsample2: bad dims");
   CHECK_SRC(src, (long long)h * w, "dvc_zero_upsample2");
   CHECK_DST(out, (long long)out_h * out_w, "dvc_zero_upsample2");
+  {
+    const long long total = (long long)batch * src->channels * out_h * out_w;
+    if (out_w == 2 * w && out_h == 2 * h && out_w % 4 == 0 && total / 4 < (1LL << 31) && al16(out) &&
+        reinterpret_cast<uintptr_t>(src->ptr) % 8 == 0 && src->batch_stride % 2 == 0 && src->chan_stride % 2 == 0) {
+      LAUNCH_1D(zero_upsample2_4_kernel, total / 4, stream, mk(src), mk(out), (unsigned)src->channels, (unsigned)w,
+                (unsigned)out_h, (unsigned)(out_w / 4), (unsigned)(total / 4));
+      return dvc::check_launch("zero_upsample2_4_kernel");
+    }
+  }
   LAUNCH_1D(zero_upsample2_kernel, (long long)batch * src->channels * out_h * out_w, stream, mk(src), mk(out), batch,
             h, w, out_h, out_w);
   return dvc::check_launch("zero_upsample2_kernel");
@@ -485,6 +606,14 @@ extern "C" int dvc_add_scaled(const DvcSrc* a, const DvcSrc* b, const float* sca
     DVC_REQUIRE(c->channels == a->channels, "dvc_add_scaled: channel mismatch");
   }
   CHECK_DST(out, plane, "dvc_add_scaled");
+  {
+    const long long total = (long long)batch * a->channels * plane;
+    if (plane % 4 == 0 && total / 4 < (1LL << 31) && al16(a) && al16(b) && al16(c) && al16(out)) {
+      LAUNCH_1D(add_scaled4_kernel, total / 4, stream, mk(a), mk(b), scale, c ? mk(c) : Src{nullptr, 0, 0, 0}, c ? 1 : 0,
+                mk(out), (unsigned)a->channels, (unsigned)(plane / 4), (unsigned)(total / 4));
+      return dvc::check_launch("add_scaled4_kernel");
+    }
+  }
   LAUNCH_1D(add_scaled_kernel, (long long)batch * a->channels * plane, stream, mk(a), mk(b), scale,
             c ? mk(c) : Src{nullptr, 0, 0, 0}, c ? 1 : 0, mk(out), batch, h, w);
   return dvc::check_launch("add_scaled_kernel");
@@ -496,6 +625,14 @@ extern "C" int dvc_scale_planes(const DvcSrc* x, const float* scale, const DvcDs
   const long long plane = (long long)h * w;
   CHECK_SRC(x, plane, "dvc_scale_planes");
   CHECK_DST(out, plane, "dvc_scale_planes");
+  {
+    const long long total = (long long)batch * x->channels * plane;
+    if (plane % 4 == 0 && total / 4 < (1LL << 31) && al16(x) && al16(out)) {
+      LAUNCH_1D(scale_planes4_kernel, total / 4, stream, mk(x), scale, mk(out), (unsigned)x->channels, (unsigned)(plane / 4),
+                (unsigned)(total / 4));
+      return dvc::check_launch("scale_planes4_kernel");
+    }
+  }
   LAUNCH_1D(scale_planes_kernel, (long long)batch * x->channels * plane, stream, mk(x), scale, mk(out), batch, h, w);
   return dvc::check_launch("scale_planes_kernel");
 }
