@@ -175,6 +175,15 @@ __global__ __launch_bounds__(256) void copy_kernel(Src src, Dst out, int batch, 
   }
 }
 
+// the same in 16-byte units (planes of a multiple of 4 floats, 16-byte aligned pointers and strides)
+__global__ __launch_bounds__(256) void copy4_kernel(Src src, Dst out, unsigned chans, unsigned plane4, unsigned total) {
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
+    reinterpret_cast<float4*>(out.p + (long long)n * out.bs + (long long)c * out.cs)[p4] =
+        reinterpret_cast<const float4*>(src.p + (long long)n * src.bs + (long long)c * src.cs)[p4];
+  }
+}
+
 __global__ __launch_bounds__(256) void clamp_kernel(Src src, Dst out, int batch, int h, int w, float lo, float hi) {
   const long long hw = (long long)h * w;
   DVC_FOREACH_OUT((long long)batch * src.c * hw) {
@@ -347,6 +356,13 @@ extern "C" int dvc_copy(const DvcSrc* src, const DvcDst* out, int32_t batch, int
   DVC_CHECK_SRC(src, h, w, "dvc_copy");
   DVC_CHECK_DST(out, (int64_t)h * w, "dvc_copy");
   const long long total = (long long)batch * src->channels * h * w;
+  if (((long long)h * w) % 4 == 0 && total / 4 < (1LL << 31) && reinterpret_cast<uintptr_t>(src->ptr) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(out->ptr) % 16 == 0 && src->batch_stride % 4 == 0 && src->chan_stride % 4 == 0 &&
+      out->batch_stride % 4 == 0 && out->chan_stride % 4 == 0) {
+    hipLaunchKernelGGL(copy4_kernel, dim3(stream_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, mk(src), mk(out),
+                       (unsigned)src->channels, (unsigned)((long long)h * w / 4), (unsigned)(total / 4));
+    return dvc::check_launch("copy4_kernel");
+  }
   hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(src), mk(out),
                      batch, h, w);
   return dvc::check_launch("copy_kernel");
