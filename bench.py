@@ -34,7 +34,12 @@ PEAK_HBM_GBS = 8000.0           # HBM3E peak (roof of the --precision bf16 optio
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one process per GPU).  Started without a launcher and N > 1, the script starts "
+                         "its own `torch.distributed.run --nproc-per-node N` as a child process")
+    ap.add_argument("--dry-run", type=int, default=0,
+                    help="1: rehearse the rank set-up, GOP assignment, barriers and the max-over-ranks timing on the "
+                         "CPU with the gloo backend; no GPU is touched and no frame is coded")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--height", type=int, default=1080)
@@ -222,17 +227,55 @@ def pad64(v):
     return (v + 63) // 64 * 64
 
 
+def dry_run(args, world, rank):
+    """The multi-rank skeleton of main() without a GPU: same GOP numbering, barriers and timing
+    reduction, gloo instead of RCCL.  Rank 0 prints the JSON line with the ranks that took part."""
+    from deepvideocodec_amd import launch
+    dist = launch.init_process_group(world, "gloo")
+    G = max(1, args.gops_in_flight)
+    mine = [(s * world + rank) * G + g for s in range(args.warmup + args.steps) for g in range(G)]
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps)
+    if dist is not None:
+        dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0, float(rank)], dtype=torch.float64)
+    ranks, gops = [rank], [mine]
+    if dist is not None:
+        tt = elapsed[:1].clone()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed[0] = tt[0]
+        ranks = [None] * world
+        gops = [None] * world
+        dist.all_gather_object(ranks, rank)
+        dist.all_gather_object(gops, mine)
+    if rank == 0:
+        flat = sorted(g for gg in gops for g in gg)
+        assert flat == list(range(len(flat))), "GOP numbering must cover 0..n-1 exactly once"
+        n_p = args.gop - 1
+        print(json.dumps({"metric": "encode frames/sec + bpp@PSNR, 1080p GOP=12, 1/2/4/8 MI355X", "dry_run": True,
+                          "value": n_p * args.steps * world * G / elapsed[0].item(), "unit": "frames/s (no frame coded)",
+                          "n_gpus": world, "world_size": world, "ranks": sorted(ranks), "backend": "gloo",
+                          "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "gops": len(flat)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    from deepvideocodec_amd import launch
+    # N > 1 without a launcher: start the ranks as a child process (before anything touches the GPU)
+    world = launch.resolve_world(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_devices=not args.dry_run)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    launch.init_process_group(world, "nccl", dev)
 
     from deepvideocodec_amd import ops
     from deepvideocodec_amd.models import DMC
@@ -380,7 +423,8 @@ def main():
             roof["all_conv_variants"].pop("frac")
         out = {
             "metric": "encode frames/sec + bpp@PSNR, 1080p GOP=12, 1/2/4/8 MI355X",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": fps, "unit": "frames/s", "n_gpus": world, "world_size": world,
+            "backend": "rccl" if world > 1 else "none (single process)", "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else args.precision + " operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"DMC {args.height}x{args.width} (padded {pad64(args.height)}x{pad64(args.width)}) "

@@ -2,7 +2,8 @@
 """Training-step benchmark of the DMC path (the reference's training workload, dmc/train.sh +
 dmc/train.py:285-346): T frames of HxW random crops, batch B per GPU, joint stage (epoch >= 40),
 lambda 2048, Adam 1e-4 / aux 1e-3, clip 1.0.  One process per GPU; under
-`python -m torch.distributed.run --nproc-per-node N tools/train_bench.py ...` the gradients are
+`python -m torch.distributed.run --nproc-per-node N tools/train_bench.py --gpus N ...` (or plain
+`python tools/train_bench.py --gpus N`, which starts that launcher itself) the gradients are
 averaged with bucketed RCCL all-reduces.  Prints one JSON line from rank 0.
 """
 import argparse
@@ -24,15 +25,16 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--epoch", type=int, default=45, help="selects the training stage (dmc/train.py:298-330)")
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one process per GPU); N > 1 without a launcher starts torch.distributed.run itself")
     args = ap.parse_args()
+    from deepvideocodec_amd import launch
+    world = launch.resolve_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    launch.init_process_group(world, "nccl", dev)
 
     from deepvideocodec_amd import train as TR
     from deepvideocodec_amd.models import DMC
@@ -71,7 +73,8 @@ def main():
         fwd_tflop = 0.2169 * (args.size * args.size) / (256.0 * 256.0) * p_frames * args.batch
         print(json.dumps({
             "metric": "training samples/s (T=%d, %dx%d crops, joint stage)" % (args.frames, args.size, args.size),
-            "value": args.batch * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": args.batch * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "world_size": world,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "batch_per_gpu": args.batch,
             "approx_tflops_per_gpu": 3 * fwd_tflop / (el / args.steps), "last_step": stats,
             "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "f32", "data": "synthetic"}), flush=True)
