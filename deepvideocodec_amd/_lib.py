@@ -69,6 +69,7 @@ SIGNATURES = {
     "dvc_spynet_level_input": (C.c_int, [_SRC, _SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_se_scratch_floats": (_i64, [_i32, _i32]),
     "dvc_se_gate": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _i32, _P, _P, _P]),
+    "dvc_se_gate_static": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _i32, _P, _P]),
     "dvc_copy": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_clamp": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _f32, _P]),
     "dvc_eb_forward": (C.c_int, [_SRC, _P, _P, _P, _DST, _DST, _P, _i32, _i32, _i32, _P]),

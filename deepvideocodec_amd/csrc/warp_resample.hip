@@ -4,6 +4,8 @@
 // One lane per output pixel (consecutive lanes = consecutive x, so loads and
 // stores of a wave are contiguous 256-byte rows); channels are looped inside the
 // lane so the per-pixel coordinate math is done once for all channels.
+#include <atomic>
+
 #include "dvc_common.h"
 
 namespace {
@@ -342,6 +344,60 @@ extern "C" int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w,
   DVC_CHECK_SRC(x, h, w, "dvc_se_gate");
   DVC_REQUIRE(x->channels <= 256 && hidden >= 1 && hidden <= 64, "dvc_se_gate: channels<=256, hidden<=64 required");
   DVC_REQUIRE(fc1 && fc2 && partial && gate, "dvc_se_gate: null pointer");
+  hipLaunchKernelGGL(plane_partial_sum_kernel, dim3(SE_SLICES, x->channels, batch), dim3(256), 0, (hipStream_t)stream,
+                     mk(x), h, w, partial);
+  int rc = dvc::check_launch("plane_partial_sum_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, x->channels,
+                     hidden, 1.0f / ((float)h * (float)w), fc1, fc2, gate);
+  return dvc::check_launch("se_fc_kernel");
+}
+
+// ---- squeeze-excite gate without any allocation: the partial sums live in a file-scope device array.
+// Each GPU the library runs on holds its own copy of the array (at its own address) until the process ends.
+constexpr int SE_STATIC_MAX_PLANES = DVC_SE_STATIC_MAX_PLANES;
+static __device__ __align__(256) float scratch[SE_STATIC_MAX_PLANES * SE_SLICES];   // 1 MiB
+
+namespace {
+// Device address of `scratch` per GPU.  In host code the array's name is only a handle for the symbol
+// lookup, not a device address: kernels get the looked-up pointer as an argument.
+std::atomic<float*> g_scratch_ptr[DVC_MAX_DEVICES];
+
+int static_scratch(float** out) {
+  int device = -1;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess || device < 0 || device >= DVC_MAX_DEVICES) {
+    dvc::set_error("dvc_se_gate_static: no current device (%s)", e != hipSuccess ? hipGetErrorString(e) : "index out of range");
+    return DVC_EHIP;
+  }
+  float* p = g_scratch_ptr[device].load(std::memory_order_acquire);
+  if (p == nullptr) {   // first call on this device (two threads racing here look up the same address)
+    void* sym = nullptr;
+    e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || sym == nullptr) {
+      dvc::set_error("dvc_se_gate_static: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+      return DVC_EHIP;
+    }
+    p = static_cast<float*>(sym);
+    g_scratch_ptr[device].store(p, std::memory_order_release);
+  }
+  *out = p;
+  return DVC_OK;
+}
+}  // namespace
+
+extern "C" int dvc_se_gate_static(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1,
+                                  const float* fc2, int32_t hidden, float* gate, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_se_gate_static: bad dims");
+  DVC_CHECK_SRC(x, h, w, "dvc_se_gate_static");
+  DVC_REQUIRE(x->channels <= 256 && hidden >= 1 && hidden <= 64, "dvc_se_gate_static: channels<=256, hidden<=64 required");
+  DVC_REQUIRE((int64_t)batch * x->channels <= SE_STATIC_MAX_PLANES,
+              "dvc_se_gate_static: batch * channels = %lld exceeds the built-in scratch (%d planes); use dvc_se_gate "
+              "with caller-provided scratch", (long long)batch * x->channels, SE_STATIC_MAX_PLANES);
+  DVC_REQUIRE(fc1 && fc2 && gate, "dvc_se_gate_static: null pointer");
+  float* partial = nullptr;
+  if (int rc = static_scratch(&partial)) return rc;
+  // every (n, c, slice) partial sum this call reads is written by its first kernel: nothing to clear
   hipLaunchKernelGGL(plane_partial_sum_kernel, dim3(SE_SLICES, x->channels, batch), dim3(256), 0, (hipStream_t)stream,
                      mk(x), h, w, partial);
   int rc = dvc::check_launch("plane_partial_sum_kernel");

@@ -58,17 +58,22 @@ def _psnr(x: torch.Tensor, rec: torch.Tensor) -> float:
     return -10.0 * math.log10(mse) if mse > 0 else float("inf")
 
 
-def code_gop(net, frames: Sequence[torch.Tensor], fd, intra: Callable, clamp: Callable) -> Tuple[int, float]:
-    """Code one GOP into fd; returns (bytes written, sum of per-frame PSNR)."""
+def code_gop(net, frames: Sequence[torch.Tensor], fd, intra: Callable, clamp: Callable) -> Tuple[int, float, int]:
+    """Code one GOP into fd; returns (bytes written, sum of per-frame PSNR, frames counted).
+
+    An intra frame that was passed through uncoded (`RawIntra`: zero bytes, zero error, PSNR infinite)
+    is left out of the PSNR sum and of the frame count, so the statistics describe the frames that were
+    actually coded; with a real intra codec every frame counts, as in the reference (dmc/test.py:205-217)."""
     size = (frames[0].size(2), frames[0].size(3))
-    nbytes, sum_psnr, dpb = 0, 0.0, None
+    nbytes, sum_psnr, counted, dpb = 0, 0.0, 0, None
     for fi, x in enumerate(frames):
         x_pad = pad(x)
         if fi == 0:
             rec_pad, enc = intra(x_pad)
-            if enc is not None:
-                nbytes += bitstream.write_body(fd, enc["shape"], enc["strings"])
             dpb = {"x_ref": rec_pad, "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+            if enc is None:
+                continue
+            nbytes += bitstream.write_body(fd, enc["shape"], enc["strings"])
         else:
             enc = net.encode_inter(x_pad, dpb)
             rec_pad, info = net.decode_inter(enc["strings"], enc["shape"], dpb)
@@ -77,15 +82,16 @@ def code_gop(net, frames: Sequence[torch.Tensor], fd, intra: Callable, clamp: Ca
                    "y_mv_ref": info["y_mv_ref"]}
             nbytes += bitstream.write_p_frame(fd, enc)
         sum_psnr += _psnr(x, crop(rec_pad, size))
-    return nbytes, sum_psnr
+        counted += 1
+    return nbytes, sum_psnr, counted
 
 
 def evaluate_sequence(net, frames: Sequence[torch.Tensor], gop: int = 32, intra: Optional[Callable] = None,
                       name: str = "sequence", quality: int = 0) -> Tuple[OrderedDict, List[Tuple[int, bytes]]]:
     """Code a sequence GOP by GOP; returns (stats, this rank's [(gop index, bitstream segment)]).
 
-    stats has the reference's keys (dmc/test.py:219-223): video, quality, bpp, psnr -- over all ranks.
-    """
+    stats has the reference's keys (dmc/test.py:219-223): video, quality, bpp, psnr -- over all ranks and
+    over the frames that were coded (see code_gop)."""
     import torch.distributed as dist
     intra = intra or RawIntra()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
@@ -100,12 +106,13 @@ def evaluate_sequence(net, frames: Sequence[torch.Tensor], gop: int = 32, intra:
         for g in sharding.gops_of_rank(len(ranges), rank, world):
             s, e = ranges[g]
             fd = io.BytesIO()
-            b, p = code_gop(net, frames[s:e], fd, intra, clamp)
+            b, p, c = code_gop(net, frames[s:e], fd, intra, clamp)
             segments.append((g, fd.getvalue()))
-            nbytes, sum_psnr, count = nbytes + b, sum_psnr + p, count + (e - s)
+            nbytes, sum_psnr, count = nbytes + b, sum_psnr + p, count + c
     dev = frames[0].device if frames[0].is_cuda else None
     nbytes, sum_psnr, count = sharding.reduce_stats(nbytes, sum_psnr, count, device=dev)
     h, w = frames[0].size(2), frames[0].size(3)
+    count = max(count, 1)
     stats = OrderedDict(video=name, quality=quality, bpp=nbytes * 8.0 / (h * w * count), psnr=sum_psnr / count)
     return stats, segments
 

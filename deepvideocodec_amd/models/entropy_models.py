@@ -166,9 +166,12 @@ class EntropyBottleneck(EntropyModel):
         noise = None
         if training:
             noise = uniform_noise(x.shape, x.device)
-        if torch.is_grad_enabled() and noise is not None:
+        if torch.is_grad_enabled():
             from .. import autograd as A
-            return A.eb_likelihood(x, self.packed_parameters(differentiable=True), self._medians_flat(), noise)
+            # evaluation mode under autograd: the likelihood is taken at round(x - median) + median, so no
+            # gradient reaches x through it (round), but the density parameters still get theirs
+            return A.eb_likelihood(x if noise is not None else x.detach(), self.packed_parameters(differentiable=True),
+                                   self._medians_flat(), noise)
         out, lik, _ = ops.eb_forward(x, self.packed_parameters(), self._medians_flat(), noise=noise)
         return out, lik
 

@@ -222,11 +222,12 @@ class _DualPriorContextModel(CompressionModel):
         eb = self.entropy_bottleneck
         z = self.hyper_encoder(y)
         z_hat_or_noisy, z_likelihoods = eb(z)
-        if self.training:  # the rate sees z + noise, the decoder path round-STE(z) (video_model.py:220-224)
-            if grad:
-                z_hat = A.round_ste(z, eb.packed_parameters(), eb._medians_flat())
-            else:
-                z_hat, _, _ = ops.eb_forward(z, eb.packed_parameters(), eb._medians_flat(), want_likelihood=False)
+        # the decoder path always sees round-STE(z - median) + median (video_model.py:220-224), whatever the
+        # rate was computed on (z + noise in training mode)
+        if grad:
+            z_hat = A.round_ste(z, eb.packed_parameters(), eb._medians_flat())
+        elif self.training:
+            z_hat, _, _ = ops.eb_forward(z, eb.packed_parameters(), eb._medians_flat(), want_likelihood=False)
         else:
             z_hat = z_hat_or_noisy
         means, scales = self._prior_params(z_hat, y_ref, context)

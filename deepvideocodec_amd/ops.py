@@ -35,6 +35,26 @@ def _check4(t: Tensor, name: str, dtype=torch.float32):
         raise ValueError(f"{name}: rows must be contiguous (strides {t.stride()})")
 
 
+def _check_vec(t: Optional[Tensor], numel: Optional[int], name: str, dtype=torch.float32, device=None):
+    """A flat parameter-like operand handed to the library as a raw pointer (bias, gates, packed
+    weights, tables): must be a contiguous GPU tensor of the stated dtype and element count, on the
+    same device as the data -- anything else would be an out-of-bounds device read."""
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.DvcError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, the data is on {device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous (strides {t.stride()})")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got {t.numel()} (shape {tuple(t.shape)})")
+
+
 def _bs(t: Tensor) -> int:
     return t.stride(0) if t.size(0) > 1 else t.size(1) * max(t.stride(1), t.size(2) * t.size(3))
 
@@ -127,6 +147,8 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
     p.batch, p.in_h, p.in_w = n, h, w
     if packed is None:
         packed = pack_conv_weight(weight, stride, precision=precision)
+    _check_vec(packed, None, "conv2d packed weight", device=weight.device)
+    _check_vec(bias, cout, "conv2d bias", device=weight.device)
     p.weight_packed = packed.data_ptr()
     p.precision = int(precision)
     p.bias = _ptr(bias)
@@ -147,8 +169,9 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
         p.res_batch_stride = _bs(residual)
         p.res_chan_stride = _cs(residual)
     if res_scale is not None:
-        if residual is None or res_scale.numel() != n * oshape[1] or not res_scale.is_contiguous():
-            raise ValueError("conv2d: res_scale needs a residual and N*C contiguous entries")
+        if residual is None:
+            raise ValueError("conv2d: res_scale needs a residual")
+        _check_vec(res_scale, n * oshape[1], "conv2d res_scale", device=weight.device)
         p.res_scale = res_scale.data_ptr()
     if residual2 is not None:
         if residual is None or tuple(residual2.shape) != oshape:
@@ -167,6 +190,8 @@ def flow_warp(src: Tensor, flow: Tensor, out: Optional[Tensor] = None) -> Tensor
         raise ValueError(f"flow_warp: flow shape {tuple(flow.shape)} != {(n, 2, h, w)}")
     if out is None:
         out = torch.empty_like(src, memory_format=torch.contiguous_format)
+    elif tuple(out.shape) != (n, c, h, w):
+        raise ValueError(f"flow_warp: out shape {tuple(out.shape)} != {(n, c, h, w)}")
     check(_lib.load().dvc_flow_warp(C.byref(_src(src)), C.byref(_src(flow, "flow")), C.byref(_dst(out)),
                                     n, h, w, _stream()), "dvc_flow_warp")
     return out
@@ -207,6 +232,12 @@ def spynet_level_input(im1: Tensor, im2: Tensor, flow_prev: Optional[Tensor]) ->
 def se_gate(x: Tensor, fc1: Tensor, fc2: Tensor) -> Tensor:
     """sigmoid(fc2 @ relu(fc1 @ mean_hw(x))) -> (N*C,) gate."""
     n, c, h, w = x.shape
+    if fc1.dim() != 2 or fc1.size(1) != c:
+        raise ValueError(f"se_gate: fc1 shape {tuple(fc1.shape)} does not match {c} channels")
+    _check_vec(fc1, fc1.size(0) * c, "se_gate fc1", device=x.device)
+    _check_vec(fc2, c * fc1.size(0), "se_gate fc2", device=x.device)
+    if tuple(fc2.shape) != (c, fc1.size(0)):
+        raise ValueError(f"se_gate: fc2 shape {tuple(fc2.shape)} != {(c, fc1.size(0))}")
     lib = _lib.load()
     partial = torch.empty(lib.dvc_se_scratch_floats(n, c), dtype=torch.float32, device=x.device)
     gate = torch.empty(n * c, dtype=torch.float32, device=x.device)
@@ -235,6 +266,9 @@ def eb_forward(z: Tensor, packed: Tensor, medians: Tensor, noise: Optional[Tenso
                want_likelihood=True, want_symbols=False):
     """-> (z_hat, likelihood | None, symbols | None)"""
     n, c, h, w = z.shape
+    _check_vec(packed, c * _lib.EB_PARAMS_PER_CHANNEL, "eb_forward packed parameters", device=z.device)
+    _check_vec(medians, c, "eb_forward medians", device=z.device)
+    _check_vec(noise, n * c * h * w, "eb_forward noise", device=z.device)
     z_hat = torch.empty((n, c, h, w), dtype=torch.float32, device=z.device)
     lik = torch.empty_like(z_hat) if want_likelihood else None
     sym = torch.empty((n, c, h, w), dtype=torch.int32, device=z.device) if want_symbols else None
@@ -248,6 +282,8 @@ def eb_forward(z: Tensor, packed: Tensor, medians: Tensor, noise: Optional[Tenso
 
 def eb_dequantize(symbols: Tensor, medians: Tensor) -> Tensor:
     n, c, h, w = symbols.shape
+    _check_vec(symbols, None, "eb_dequantize symbols", dtype=torch.int32)
+    _check_vec(medians, c, "eb_dequantize medians", device=symbols.device)
     z_hat = torch.empty((n, c, h, w), dtype=torch.float32, device=symbols.device)
     check(_lib.load().dvc_eb_dequantize(symbols.data_ptr(), medians.data_ptr(), C.byref(_dst(z_hat)), n, c, h, w,
                                         _stream()), "dvc_eb_dequantize")
@@ -280,6 +316,7 @@ def dual_prior_pass2(y: Tensor, means: Tensor, scales: Tensor, spatial: Tensor, 
     if "symbols" in want:
         if scale_table is None:
             raise ValueError("dual_prior_pass2: scale_table required for symbols/indexes")
+        _check_vec(scale_table, None, "dual_prior_pass2 scale_table", device=y.device)
         sym = torch.empty((2, n, c // 2, h, w), dtype=torch.int32, device=y.device)
         idx = torch.empty_like(sym)
         res["symbols"], res["indexes"] = sym, idx
@@ -295,6 +332,7 @@ def dual_prior_pass2(y: Tensor, means: Tensor, scales: Tensor, spatial: Tensor, 
 
 def dual_prior_dec_indexes(s: Tensor, plane: int, channels: int, scale_table: Tensor) -> Tensor:
     n, _, h, w = s.shape
+    _check_vec(scale_table, None, "dual_prior_dec_indexes scale_table", device=s.device)
     idx = torch.empty((n, channels // 2, h, w), dtype=torch.int32, device=s.device)
     check(_lib.load().dvc_dual_prior_dec_indexes(C.byref(_src(s)), plane, idx.data_ptr(), scale_table.data_ptr(),
                                                  scale_table.numel(), n, channels, h, w, _stream()),

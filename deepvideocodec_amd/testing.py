@@ -42,12 +42,28 @@ def seeded_state_dict(seed: int = 0, ch_mv: int = 64, N: int = 64, M: int = 96,
     calibrated=False is the raw reference-style init (activations grow to ~1e4)."""
     sd = _raw_seeded_state_dict(seed, ch_mv, N, M)
     if calibrated:
-        cal = _calibration(seed)
-        for name, g in cal["gain"].items():
-            sd[name + ".weight"] = sd[name + ".weight"] * g
-            sd[name + ".bias"] = sd[name + ".bias"] * g
-        for name, shift in cal["bias_shift"].items():
-            sd[name + ".bias"] = sd[name + ".bias"] + torch.tensor(shift)
+        sd = apply_calibration(sd, _calibration(seed))
+    return sd
+
+
+def apply_calibration(sd: Dict[str, torch.Tensor], cal) -> Dict[str, torch.Tensor]:
+    """A copy of the raw seeded state dict with the calibration applied:
+    conv weight *= gain (a scalar, or one value per output channel), bias = bias * gain + bias_shift;
+    the first matrix of each factorised prior is sharpened per channel (softplus(m') = k softplus(m),
+    i.e. the density gets k times narrower)."""
+    sd = dict(sd)
+    for name, g in cal["gain"].items():
+        g = torch.as_tensor(g, dtype=torch.float32)
+        sd[name + ".weight"] = sd[name + ".weight"] * (g.view(-1, 1, 1, 1) if g.dim() else g)
+        sd[name + ".bias"] = sd[name + ".bias"] * g
+    for name, shift in cal["bias_shift"].items():
+        sd[name + ".bias"] = sd[name + ".bias"] + torch.as_tensor(shift, dtype=torch.float32)
+    for key, k in cal.get("eb_sharpen", {}).items():
+        name = f"{key}.entropy_bottleneck._matrix0"
+        m = sd[name].double()
+        target = torch.as_tensor(k, dtype=torch.float64).view(-1, 1, 1) * torch.nn.functional.softplus(m)
+        # inverse softplus; for large arguments log(expm1(t)) == t to double precision
+        sd[name] = torch.where(target > 30.0, target, torch.log(torch.expm1(target.clamp(max=30.0)))).float()
     return sd
 
 

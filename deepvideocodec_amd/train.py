@@ -128,14 +128,24 @@ def stage_of_epoch(epoch: int) -> Tuple[bool, bool, str]:
 
 def all_reduce_gradients(parameters: Iterable[Tensor], bucket_bytes: int = 32 << 20, group=None) -> int:
     """Average .grad over the ranks of the process group: gradients are packed into flat buckets of
-    about `bucket_bytes`, one all-reduce (RCCL on GPUs) per bucket, then unpacked.  Parameters
-    without a gradient on this rank contribute zeros (every rank must issue the same collectives).
+    about `bucket_bytes`, one all-reduce (RCCL on GPUs) per bucket, then unpacked.
+
+    Which parameters take part is decided globally: one small all-reduce (MAX) of a presence mask tells
+    every rank which parameters received a gradient on at least one rank.  Those are reduced (a rank
+    without a gradient for one of them contributes zeros); a parameter no rank has a gradient for keeps
+    `.grad = None`, exactly as in a single-process run -- so the optimizer skips it (no Adam state, no
+    step count) in the stages that train only part of the model (dmc/train.py:298-330).
     Returns the number of buckets; a no-op (0) without an initialised process group."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
     params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return 0
+    have = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=params[0].device)
+    dist.all_reduce(have, op=dist.ReduceOp.MAX, group=group)
+    params = [p for p, h in zip(params, have.tolist()) if h]
     buckets: List[List[Tensor]] = [[]]
     size = 0
     for p in params:

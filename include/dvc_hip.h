@@ -149,6 +149,21 @@ int64_t dvc_se_scratch_floats(int32_t batch, int32_t channels);
 int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1,
                 const float* fc2, int32_t hidden, float* partial, float* gate, void* stream);
 
+/*
+ * dvc_se_gate for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arithmetic and
+ * the same kernels as dvc_se_gate, but the partial plane sums go to a device array built into the library
+ * (1 MiB per GPU, held until the process ends) instead of caller scratch, and the call itself makes no
+ * hipMalloc / hipFree.  Limit: batch * channels <= DVC_SE_STATIC_MAX_PLANES, larger inputs are rejected with
+ * DVC_EINVAL.  All calls on one GPU share that array: calls that overlap in time on the same GPU (different
+ * streams) race; calls on one stream are ordered.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress); make that first call outside of a graph capture.
+ */
+#define DVC_SE_STATIC_MAX_PLANES 4096
+#define DVC_MAX_DEVICES 64
+int dvc_se_gate_static(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1,
+                       const float* fc2, int32_t hidden, float* gate, void* stream);
+
 /* Plain strided copy / elementwise helpers. */
 int dvc_copy(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream);
 int dvc_clamp(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,

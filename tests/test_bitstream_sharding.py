@@ -114,5 +114,7 @@ def test_sharded_evaluation_equals_single_process():
     assert sharding.order_segments(segs) == sharding.order_segments(ref_segs)
     for _, stats, _ in got:   # every rank holds the all-rank statistics
         assert stats["bpp"] == pytest.approx(ref_stats["bpp"], rel=1e-12)
-        assert stats["psnr"] == pytest.approx(ref_stats["psnr"], rel=1e-9)
+        # (finite: the uncoded intra pictures are not counted; the ranks run the oracle with another thread
+        # count than the single process, so the fp32 reconstructions differ in the last bits)
+        assert stats["psnr"] == pytest.approx(ref_stats["psnr"], rel=1e-6) and stats["psnr"] < 100
     assert ref_stats["bpp"] > 0 and list(ref_stats.keys()) == ["video", "quality", "bpp", "psnr"]

@@ -1,0 +1,65 @@
+"""Free-running whole-GOP parity: the evaluation loop of dmc/test.py:162-196 (encode_inter ->
+decode_inter -> clamp -> buffer update, the buffer carried from frame to frame) run independently on the
+GPU product path and on the CPU oracle -- no teacher forcing, so any error feeds forward through the
+decoded-picture buffer for 11 (GOP 12) or 31 (GOP 32, the reference's hard-coded intra period) frames.
+
+Asserted on the GOP average: |dPSNR| <= 1e-3 dB and |dbpp| <= 1e-4, bpp from the bytes actually written
+(dmc/test.py:213-217).  The per-frame drift is printed."""
+import math
+
+import pytest
+import torch
+
+from oracle import dmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def psnr(x, rec):
+    return -10.0 * math.log10(torch.mean((x.double() - rec.double()) ** 2).item())
+
+
+def _code_gop(enc_fn, dec_fn, frames, to_dev, clamp):
+    dpb = {"x_ref": to_dev(frames[0]), "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    per_frame = []
+    for x in frames[1:]:
+        enc = enc_fn(to_dev(x), dpb)
+        rec, info = dec_fn(enc["strings"], enc["shape"], dpb)
+        rec = clamp(rec)
+        nbytes = sum(len(s[0]) for v in enc["strings"].values() for s in v)
+        per_frame.append((nbytes, psnr(x, rec.cpu()), enc["strings"]))
+        dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"], "y_mv_ref": info["y_mv_ref"]}
+    return per_frame
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("gop,size,seed", [(12, 256, 31), (32, 128, 32)])
+def test_free_running_gop_matches_oracle(gpu_net, seeded_sd, oracle_entropy, gop, size, seed):
+    from deepvideocodec_amd import ops
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = synthetic_gop(gop, size, size, seed=seed)
+    n_pix = size * size
+    with torch.no_grad():
+        got = _code_gop(gpu_net.encode_inter, gpu_net.decode_inter, frames, lambda t: t.cuda(),
+                        lambda t: ops.clamp(t, 0.0, 1.0))
+        ref = _code_gop(lambda x, d: O.encode_inter(seeded_sd, oracle_entropy, x, d),
+                        lambda s, sh, d: O.decode_inter(seeded_sd, oracle_entropy, s, sh, d), frames, lambda t: t,
+                        lambda t: t.clamp(0, 1))
+    lines, first_diff = [], None
+    for i, ((bg, pg, sg), (br, pr, sr)) in enumerate(zip(got, ref), start=1):
+        same = sg == sr
+        if not same and first_diff is None:
+            first_diff = i
+        lines.append(f"frame {i:2d}: bytes {bg:6d} vs {br:6d}, PSNR {pg:.5f} vs {pr:.5f} (d {pg - pr:+.1e}) "
+                     f"{'identical streams' if same else 'streams differ'}")
+    print("\n".join(lines))
+    n = len(got)
+    bpp_g = 8.0 * sum(b for b, _, _ in got) / (n_pix * n)
+    bpp_r = 8.0 * sum(b for b, _, _ in ref) / (n_pix * n)
+    psnr_g = sum(p for _, p, _ in got) / n
+    psnr_r = sum(p for _, p, _ in ref) / n
+    print(f"GOP {gop} at {size}x{size}: GPU {bpp_g:.5f} bpp {psnr_g:.4f} dB | oracle {bpp_r:.5f} bpp {psnr_r:.4f} dB | "
+          f"first differing stream: {first_diff}")
+    assert 0.02 <= bpp_r <= 1.5, bpp_r
+    assert abs(psnr_g - psnr_r) <= 1e-3, (psnr_g, psnr_r)
+    assert abs(bpp_g - bpp_r) <= 1e-4, (bpp_g, bpp_r)

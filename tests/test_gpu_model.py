@@ -94,21 +94,31 @@ def _near_tie(pre, tol=2e-3):
     return (frac - 0.5).abs() <= tol * pre.abs().clamp_min(1.0)
 
 
-def _explained_by_ties(got_hat, trace):
-    """A mismatch in quantised latents is legitimate only if it starts at a genuine fp32 rounding
-    tie: either the differing y elements themselves are near-ties (and few), or a hyper-latent z
-    element was a near-tie (which then moves every mean/scale)."""
-    # y_hat = round(y - mu) + mu: equal symbols give values equal to ~1e-5, a flipped symbol
-    # moves the value by a whole step
+def _explained_by_ties(got_hat, trace, got_z_lik=None, ref_z_lik=None):
+    """A mismatch in quantised latents is legitimate only if it starts at a genuine fp32 rounding tie.
+
+    Hyper-latents: the z symbols that differ (seen through their likelihoods: another symbol has another
+    probability) must THEMSELVES be near-ties in the oracle's pre-rounding values; a differing z element
+    moves every mean / scale in its neighbourhood, so it explains the y differences of the frame.
+    Latents (no z difference): at least one differing y element is a near-tie, and every other differing
+    element lies within the 7x7 receptive field of the spatial prior (three 3x3 layers) around such a
+    tie -- the second checkerboard pass sees the flipped first-pass value.  Returns (ok, n_diff)."""
+    # y_hat = round(y - mu) + mu: equal symbols give values equal to ~1e-5, a flipped symbol moves the
+    # value by a whole step
     diff = (got_hat - trace["y_hat"]).abs() > 0.5
     n_diff = int(diff.sum())
+    if got_z_lik is not None:
+        z_diff = (got_z_lik - ref_z_lik).abs() > 1e-3 * ref_z_lik.abs().clamp_min(1e-6)
+        if bool(z_diff.any()):
+            ok = int(z_diff.sum()) <= 4 and bool(_near_tie(trace["z_pre"])[z_diff].all())
+            return ok, max(n_diff, int(z_diff.sum()))
     if n_diff == 0:
         return True, 0
-    if n_diff <= 8 and bool(_near_tie(trace["y_pre"])[diff].all()):
-        return True, n_diff
-    if bool(_near_tie(trace["z_pre"]).any()):
-        return True, n_diff
-    return False, n_diff
+    ties = diff & _near_tie(trace["y_pre"])
+    if not bool(ties.any()) or int(ties.sum()) > 8:
+        return False, n_diff
+    near = torch.nn.functional.max_pool2d(ties.any(dim=1, keepdim=True).float(), 7, stride=1, padding=3) > 0
+    return bool((diff.any(dim=1, keepdim=True) <= near).all()), n_diff
 
 
 def test_forward_vs_oracle_128_batch2(gpu_net, seeded_sd, oracle_entropy):
@@ -133,12 +143,14 @@ def test_forward_vs_oracle_128_batch2(gpu_net, seeded_sd, oracle_entropy):
             sl = slice(b, b + 1)
             tr_m = {k: v[sl] for k, v in trace["motion_context_model"].items()}
             tr_f = {k: v[sl] for k, v in trace["frame_context_model"].items()}
-            ok_m, n_m = _explained_by_ties(ctx_g["y_mv_ref"][sl].cpu(), tr_m)
+            ok_m, n_m = _explained_by_ties(ctx_g["y_mv_ref"][sl].cpu(), tr_m, lik_g["motion"]["z"][sl].cpu(),
+                                           lik_o["motion"]["z"][sl])
             assert ok_m, f"frame {i} batch {b}: {n_m} motion latents differ without a rounding tie"
             if n_m:
                 flips += 1
                 continue
-            ok_f, n_f = _explained_by_ties(ctx_g["y_ref"][sl].cpu(), tr_f)
+            ok_f, n_f = _explained_by_ties(ctx_g["y_ref"][sl].cpu(), tr_f, lik_g["frame"]["z"][sl].cpu(),
+                                           lik_o["frame"]["z"][sl])
             assert ok_f, f"frame {i} batch {b}: {n_f} frame latents differ without a rounding tie"
             if n_f:
                 flips += 1
@@ -168,9 +180,9 @@ def test_decode_reproduces_encoder_state(gpu_net):
     # actual bytes are close to the likelihood estimate
     est = sum(bits(t.cpu()) for v in lik.values() for t in v.values())
     act = 8 * sum(len(s[0]) for v in enc["strings"].values() for s in v)
-    # (an untrained model's estimate is pessimistic: the 1e-9 likelihood floor prices an outlier at
-    # 29.9 bits while the coder's escape costs ~24)
-    assert 0.6 * est <= act <= 1.05 * est + 6 * 64
+    # six streams, each flushed with a 32-bit word granularity and an 8-byte final state: a fixed ~6 x 64 bits
+    # on top of the 2 % the quantised CDF tables may cost at this small size (a few kbit in all)
+    assert abs(act - est) <= 0.02 * est + 6 * 64, (act, est)
 
 
 def test_motion_pretrain_and_training_mode(gpu_net):
@@ -209,7 +221,7 @@ def test_full_size_round_trip_1080p(gpu_net):
         assert torch.equal(rec, fwd["x_hat"][i - 1])
         est = sum(bits(t.cpu()) for v in fwd["likelihoods"][i - 1].values() for t in v.values())
         act = 8 * sum(len(s[0]) for v in enc["strings"].values() for s in v)
-        assert 0.6 * est <= act <= 1.05 * est
+        assert abs(act - est) <= 0.02 * est, (i, act, est, act / est)
         # forward() chains on the un-clamped reconstruction (reference: video_model.py:544-549)
         dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
                "y_mv_ref": info["y_mv_ref"]}
@@ -229,16 +241,18 @@ def test_evaluation_loop_bitstream_round_trip(gpu_net, seeded_sd, oracle_entropy
     stats, segs = evaluate.evaluate_sequence(gpu_net, frames, gop=3, name="clip", quality=6)
     assert [g for g, _ in segs] == [0, 1] and list(stats) == ["video", "quality", "bpp", "psnr"]
     total = sum(len(b) for _, b in segs)
-    assert stats["bpp"] == pytest.approx(total * 8 / (70 * 100 * 5))
+    # frames 0 and 3 are the (uncoded) intra pictures of the two GOPs: three coded frames
+    assert stats["bpp"] == pytest.approx(total * 8 / (70 * 100 * 3))
+    assert math.isfinite(stats["psnr"]) and 0 < stats["psnr"] < 100
     clamp = lambda t: ops.clamp(t, 0.0, 1.0)
     # stand-alone decode of GOP 0 from its bytes reproduces the encoder-side loop
     fd = io.BytesIO(segs[0][1])
     recs = evaluate.decode_gop(gpu_net, fd, evaluate.pad(frames[0]), 3, clamp)
     assert fd.read() == b"" and len(recs) == 2
     fd2 = io.BytesIO()
-    nbytes, sum_psnr = evaluate.code_gop(gpu_net, frames[0:3], fd2, evaluate.RawIntra(), clamp)
+    nbytes, sum_psnr, counted = evaluate.code_gop(gpu_net, frames[0:3], fd2, evaluate.RawIntra(), clamp)
     assert fd2.getvalue() == segs[0][1] and nbytes == len(segs[0][1])
-    assert sum_psnr == float("inf")   # the raw intra frame has zero error, as in the reference's arithmetic
+    assert counted == 2 and math.isfinite(sum_psnr)   # the raw intra frame (zero error) is not counted
     for i, r in enumerate(recs):
         assert 0 < psnr(frames_cpu[i + 1], evaluate.crop(r, (70, 100)).cpu()) < 100
     # the oracle through the same loop
@@ -289,9 +303,11 @@ def test_config0_256x256_gop4_random_frames_vs_oracle(gpu_net, seeded_sd, oracle
         x_o, lik_o, ctx_o = O.forward_inter(seeded_sd, oracle_entropy, frames[i], dpb, trace=trace)
         dpb_g = {k: (None if v is None else v.cuda()) for k, v in dpb.items()}
         x_g, lik_g, ctx_g = gpu_net.forward_inter(frames[i].cuda(), dpb_g)
-        ok_m, n_m = _explained_by_ties(ctx_g["y_mv_ref"].cpu(), trace["motion_context_model"])
+        ok_m, n_m = _explained_by_ties(ctx_g["y_mv_ref"].cpu(), trace["motion_context_model"],
+                                       lik_g["motion"]["z"].cpu(), lik_o["motion"]["z"])
         assert ok_m, f"frame {i}: {n_m} motion latents differ without a rounding tie"
-        ok_f, n_f = _explained_by_ties(ctx_g["y_ref"].cpu(), trace["frame_context_model"])
+        ok_f, n_f = (True, 0) if n_m else _explained_by_ties(ctx_g["y_ref"].cpu(), trace["frame_context_model"],
+                                                             lik_g["frame"]["z"].cpu(), lik_o["frame"]["z"])
         assert ok_f, f"frame {i}: {n_f} frame latents differ without a rounding tie"
         if n_m == 0 and n_f == 0:
             strict += 1

@@ -1,14 +1,13 @@
 """Parity at the headline size: the first two P frames of a 1080p GOP (padded to 1088x1920) through
 the product path on the GPU against the CPU oracle on the same inputs, frame by frame from the oracle's
-decoded-picture buffer -- for the exact fp32 arithmetic and for the fp16 hi + lo split arithmetic.
+decoded-picture buffer.
 
-Tolerances: |dPSNR| <= 1e-3 dB as stated; |dbpp| <= 1e-4 * max(1, bpp).  The seeded random-init model
-codes ~5 bpp at this size (a trained codec: ~0.1) with latents in the hundreds, and round() sits in the
-middle of the graph: about 0.2-0.4 % of the 1.3 M latents lie so close to a rounding boundary that two
-fp32 implementations with different summation orders already disagree on them (measured: exact-fp32 GPU
-vs CPU 2.5-4.6 k latents, dbpp up to 1.4e-4; fp16 split 3.0-5.2 k latents, dbpp 5e-5).  The absolute 1e-4
-is asserted at the sizes where the fixtures and the oracle give identical symbols (test_gpu_model.py);
-here it is asserted relative to the rate.  The oracle needs ~10 s per frame on 16 cores."""
+Bar for the exact fp32 path (the one that carries the benchmark value), absolute, as stated for the path:
+|dPSNR| <= 1e-3 dB, |dbpp| <= 1e-4 (likelihood bpp, dmc/train.py:74-93), and at most 1e-4 of the 1.3 M
+quantised latents on the other side of a rounding boundary (round() sits in the middle of the graph; two
+fp32 implementations with different summation orders may disagree on a latent within ~1e-6 of x.5).
+The fp16 hi+lo split arithmetic (never the benchmark value) is run beside it and held to 5x those bars.
+The oracle needs ~10 s per frame on 16 cores."""
 import math
 
 import pytest
@@ -20,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 PSNR_TOL = 1e-3
 BPP_TOL = 1e-4
+N_LATENTS = 160 * 68 * 120
+FLIP_TOL = 1e-4 * N_LATENTS
 
 
 def psnr(x, rec):
@@ -42,7 +43,7 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
             for i in (1, 2):
                 x_o, lik_o, ctx_o = O.forward_inter(seeded_sd, oracle_entropy, frames[i], dpb)
                 p_o, b_o = psnr(frames[i], x_o), bpp(lik_o, n_pix)
-                rate[i] = b_o
+                rate[i] = (b_o, p_o)
                 dpb_g = {k: (None if v is None else v.cuda()) for k, v in dpb.items()}
                 for mode in ("fp32", "fp16x2"):
                     gpu_net.set_precision(mode)
@@ -53,8 +54,12 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
                 dpb = dict(ctx_o)
     finally:
         gpu_net.set_precision("fp32")
-    print("\n".join(f"frame {i} {m}: dPSNR {dp:+.2e} dB, dbpp {db:+.2e}, {fl} latents differ" for i, m, dp, db, fl in report))
+    print("\n".join(f"frame {i} {m}: oracle {rate[i][0]:.4f} bpp / {rate[i][1]:.3f} dB; dPSNR {dp:+.2e} dB, dbpp {db:+.2e}, "
+                    f"{fl} of {N_LATENTS} latents differ" for i, m, dp, db, fl in report))
+    for i, (b_o, _) in rate.items():
+        assert 0.02 <= b_o <= 1.0, f"frame {i}: {b_o} bpp is not a realistic operating point for the parity bar"
     for i, mode, d_psnr, d_bpp, flips in report:
-        assert abs(d_psnr) <= PSNR_TOL, (i, mode, d_psnr)
-        assert abs(d_bpp) <= BPP_TOL * max(1.0, rate[i]), (i, mode, d_bpp, rate[i])
-        assert flips <= 0.01 * 160 * 68 * 120, (i, mode, flips)
+        k = 1.0 if mode == "fp32" else 5.0
+        assert abs(d_psnr) <= k * PSNR_TOL, (i, mode, d_psnr)
+        assert abs(d_bpp) <= k * BPP_TOL, (i, mode, d_bpp)
+        assert flips <= k * FLIP_TOL, (i, mode, flips)

@@ -66,13 +66,15 @@ def _worker(rank, world, port, q):
         torch.manual_seed(0)
         net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
         extra = torch.nn.Parameter(torch.zeros(4))        # never receives a gradient on rank 1
-        params = list(net.parameters()) + [extra]
+        frozen_stage = torch.nn.Parameter(torch.zeros(6))  # no gradient on any rank (a stage that skips it)
+        params = list(net.parameters()) + [extra, frozen_stage]
         x = torch.full((2, 5), float(rank + 1))
         net(x).sum().backward()
         if rank == 0:
             extra.grad = torch.ones(4)
         nb = T.all_reduce_gradients(params, bucket_bytes=64)
-        q.put((rank, nb, [p.grad.clone() for p in params]))
+        assert frozen_stage.grad is None   # stays None, as in a single-process run: the optimizer skips it
+        q.put((rank, nb, [p.grad.clone() for p in params[:-1]]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
