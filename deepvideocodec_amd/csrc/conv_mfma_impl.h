@@ -82,8 +82,30 @@ struct Geo {
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
   static constexpr int STAGE_BYTES = NBUF * (IN_BUF + SLAB) * 4;
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4;   // four wave-private 32 x 36 transposition tiles
-  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  static constexpr int LDS_BYTES = MAIN_BYTES + 64 * 4;   // + this workgroup's (up to 64) bias values
 };
+
+// Diagnostic build only (-DDVC_CONV_STAMPS, tools/conv_stamps.py): wave 0 of every workgroup records the
+// clock at its phase boundaries into a buffer no other code reads.  The shipped library has no stamps.
+#ifdef DVC_CONV_STAMPS
+__device__ unsigned long long* g_conv_stamps = nullptr;
+#define DVC_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (g_conv_stamps != nullptr && threadIdx.x == 0) {                                                       \
+      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      g_conv_stamps[wg_ * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                       \
+      if ((k) == 0) {                                                                                         \
+        g_conv_stamps[wg_ * 16 + 4] = __builtin_amdgcn_s_memtime();                                           \
+        g_conv_stamps[wg_ * 16 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |         \
+                                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+      }                                                                                                       \
+      if ((k) == 3) g_conv_stamps[wg_ * 16 + 5] = __builtin_amdgcn_s_memtime();                               \
+    }                                                                                                         \
+  } while (0)
+#else
+#define DVC_STAMP(k)
+#endif
 
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
@@ -96,10 +118,12 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   constexpr int NBUF = G::NBUF, PARTS = G::PARTS;
   float* const w_s = lds;                   // [NBUF][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
   float* const in_s = lds + NBUF * SLAB;    // [NBUF][IN_BUF]
+  float* const bias_s = lds + G::MAIN_BYTES / 4;   // [CB] bias of this workgroup's channels (0 past Cout / without bias)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DVC_STAMP(0);
   // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
   // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
   // of them: the halo columns and rows shared by neighbouring tiles are then fetched into one L2
@@ -120,6 +144,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const int wblock = HALF ? (int)(blockIdx.y >> 1) : (int)blockIdx.y;   // packed weight block
   const int cb0 = HALF ? wblock * 64 + (int)(blockIdx.y & 1) * 32 : wblock * CB;
   if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
+  if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
   const int n = blockIdx.z;
   const int nchunks = (a.cin + CK - 1) / CK;
 
@@ -143,17 +168,22 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 
   float rin[CK][IN_PT];
 
-  // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves
+  // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves.
+  // Issued as buffer loads (MUBUF ... lds), not global_load_lds: the compiler treats a FLAT-family
+  // instruction that touches LDS as able to return out of order with the ds_reads and then waits for
+  // lgkmcnt(0) before every MFMA group, which exposes the LDS latency of the operand reads just issued
+  // for the next tap (10 % of the K loop for a wave alone on its SIMD).
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)SLAB), 0x00020000);
   auto dma_weights = [&](int chunk, int buf) {
-    const float* src = wslabs + (long long)chunk * SLAB;
     float* dst = w_s + buf * SLAB;
+    const unsigned soff = 4u * (unsigned)chunk * (unsigned)SLAB;
 #pragma unroll
     for (int p = 0; p < (SLAB / 256 + 3) / 4; ++p) {
       const int piece = wave + 4 * p;
       if (piece < SLAB / 256)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
-            (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                             16u * (unsigned)lane, soff + 1024u * (unsigned)piece, 0, 0);
     }
   };
 
@@ -300,8 +330,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   dma_weights(0, 0);
   prefetch_input(0);
   commit_input(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the DMA pieces have landed (a form the compiler's wait-count tracking sees) */
   __syncthreads();
+  DVC_STAMP(1);
 
   for (int k = 0; k < nchunks; ++k) {
     const int cur = NBUF == 2 ? (k & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
@@ -392,10 +423,19 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       if (k + 1 < nchunks) dma_weights(k + 1, 0);
     }
     if (k + 1 < nchunks) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed in LDS
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the DMA pieces have landed (a form the compiler's wait-count tracking sees) */   // this wave's DMA pieces have landed in LDS
     __syncthreads();
   }
 
+  DVC_STAMP(2);
+#ifdef DVC_EXP_NO_EPILOGUE   // experiment: how long the launch takes with no epilogue at all (wrong results)
+  if (a.h < 0) {
+    float sacc = 0.f;
+    for (int mt = 0; mt < MT; ++mt) for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
+    a.out[tid] = sacc;
+  }
+  return;
+#endif
   // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
   // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
   // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
@@ -431,10 +471,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
         const int cu0 = cb0 + mt * 32;
         float bias_r[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int oy = oy0 + wave * NT + nt;
@@ -492,18 +529,131 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
             }
             if (ok[q]) *reinterpret_cast<float4*>(out_n + chs[q] * a.ocs + pix[q]) = v;
           }
+          DVC_STAMP(8 + ((mt * NT + nt) & 7));
+        }
+      }
+    };
+    // The common case -- no PixelShuffle, the whole 32*MT x TH x 32 tile inside the tensor -- as one
+    // branch-free software pipeline over the MT*NT accumulator tiles of the wave: tile i is written to the
+    // wave's LDS tile and read back transposed, and while those reads are in flight tile i-1 gets its
+    // residuals added and is stored (LDS executes a wave's accesses in order, so the single tile buffer
+    // needs no waits between tiles).  Addresses are a wave-uniform base per (tile, channel octet) plus one
+    // 32-bit per-lane offset computed once; the bias comes from LDS.
+    auto run_full = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c) {
+      constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
+      constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
+      // plain: 8 lanes x 16 B per channel row; piece q of a lane = channel 8q + sub, pixels px4 .. px4+3.
+      // shuffle: conv channel co -> stored channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); 16 lanes x 16 B
+      // per stored row; piece q = stored channel 2q + (row>>1), row parity row&1, conv pixels px2, px2+1 of the
+      // two conv channels 8q + 4(row>>1) + 2(row&1) + {0, 1}.
+      const int sub = lane >> 3, px4 = 4 * (lane & 7);
+      const int row = lane >> 4, px2 = 2 * (lane & 15);
+      const long long wo2 = 2LL * a.wo;
+      const unsigned o_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.ocs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                 : (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
+      const unsigned r_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.rcs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                 : (unsigned)sub * (unsigned)a.rcs + (unsigned)px4;
+      const unsigned r2_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.r2cs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                  : (unsigned)sub * (unsigned)a.r2cs + (unsigned)px4;
+      const int lds_lane = PS ? (4 * (row >> 1) + 2 * (row & 1)) * RS + px2 : sub * RS + px4;
+      const int cq = PS ? 2 : 8;             // stored channels per piece index q
+      const int c0s = PS ? (cb0 >> 2) : cb0;   // first stored channel of the workgroup
+      const int cms = PS ? 8 : 32;           // stored channels per 32-channel accumulator group
+      const float out_slope = a.out_slope;
+      float4 cur[4], t[4];
+      float bias_r[16];
+      float sc[MT][4];
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            sc[mt][q] = a.res_scale[n * a.c_final + c0s + mt * cms + cq * q + (PS ? (row >> 1) : sub)];
+      }
+      auto tile_pix = [&](int nt) -> long long {   // wave-uniform pixel offset of the tile inside a stored plane
+        const long long oy = oy0 + wave * NT + nt;
+        return PS ? 2 * oy * wo2 + 2LL * ox0 : oy * a.wo + ox0;
+      };
+      auto finish = [&](int mt, int nt) {   // residual adds + stores of a tile whose transposed values are in `cur`
+        const long long pix = tile_pix(nt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = cur[q];
+          const long long ch = c0s + mt * cms + cq * q;   // wave-uniform stored channel of this piece (lane 0's)
+          if constexpr (RES) {
+            if constexpr (SCALE) {
+              // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
+              const float g = sc[mt][q];
+              v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, g)); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, g));
+              v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, g)); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, g));
+            } else {
+              v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
+            }
+            if constexpr (RES2) {   // (rare: loaded where it is used, to stay within the register budget)
+              const float4 u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix + r2_lane);
+              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+          }
+          *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix + o_lane) = v;
+        }
+      };
+#pragma unroll
+      for (int i = 0; i <= MT * NT; ++i) {
+        if (i < MT * NT) {
+          const int mt = i / NT, nt = i - mt * NT;
+          if (nt == 0) {   // one batch of LDS reads per 32-channel group (not one dependent read per value)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[mt][nt][r] + bias_r[r];
+            // LeakyReLU / ReLU / identity (slope 1) as max(v, v * slope): equal to the select for 0 <= slope <= 1
+            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v, v * out_slope);
+          }
+        }
+        if (i > 0) finish((i - 1) / NT, (i - 1) % NT);
+        if (i < MT * NT) {
+          const int mt = i / NT, nt = i - mt * NT;
+          // read tile i back transposed; consumed one iteration later, behind the next tile's arithmetic
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (!PS) {
+              cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
+            } else {
+              const float2 e = *reinterpret_cast<const float2*>(tl + 8 * q * RS + lds_lane);
+              const float2 o = *reinterpret_cast<const float2*>(tl + (8 * q + 1) * RS + lds_lane);
+              cur[q] = make_float4(e.x, o.x, e.y, o.y);
+            }
+          }
+          if constexpr (RES) {   // this tile's residual operands, consumed one iteration later as well
+            const long long pix = tile_pix(nt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              t[q] = *reinterpret_cast<const float4*>(res_n + (long long)(c0s + mt * cms + cq * q) * a.rcs + pix + r_lane);
+          }
         }
       }
     };
     using T = std::true_type;
     using F = std::false_type;
+    // (slopes outside [0, 1] never occur in the DMC graph; they take the general formulation below)
+    const bool full = cb0 + CB <= a.cout && ox0 + TW <= a.wo && oy0 + TH <= a.ho &&
+                      a.out_slope >= 0.f && a.out_slope <= 1.f;
     auto by_shuffle = [&](auto res_c, auto scale_c, auto res2_c) {
-      if (a.ps) run(res_c, scale_c, res2_c, T{});
-      else run(res_c, scale_c, res2_c, F{});
+      if (full) {
+        if (a.ps) run_full(res_c, scale_c, res2_c, T{});
+        else run_full(res_c, scale_c, res2_c, F{});
+      } else if (a.ps) {
+        run(res_c, scale_c, res2_c, T{});
+      } else {
+        run(res_c, scale_c, res2_c, F{});
+      }
     };
     if (!has_res) by_shuffle(F{}, F{}, F{});
     else if (has_scale) { if (has_res2) by_shuffle(T{}, T{}, T{}); else by_shuffle(T{}, T{}, F{}); }
     else { if (has_res2) by_shuffle(T{}, F{}, T{}); else by_shuffle(T{}, F{}, F{}); }
+    DVC_STAMP(3);
     return;
   }
 
