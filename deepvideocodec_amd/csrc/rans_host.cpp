@@ -100,6 +100,8 @@ extern "C" int64_t dvc_rans_encode(const int32_t* symbols, const int32_t* indexe
   }
   DVC_REQUIRE(out_capacity >= 8 && reinterpret_cast<uintptr_t>(out) % 4 == 0,
               "dvc_rans_encode: output buffer must be 4-byte aligned and hold >= 8 bytes");
+  for (int64_t i = 0; i < n; ++i)
+    DVC_REQUIRE(indexes[i] >= 0 && indexes[i] < n_cdfs, "dvc_rans_encode: index %d out of range at %lld", indexes[i], (long long)i);
   // One backward pass, words written from the end of `out` towards its start.  A symbol's
   // records go out in reverse of their decode order: raw nibbles (last first), the nibble
   // count, then the table symbol itself.
@@ -113,7 +115,6 @@ extern "C" int64_t dvc_rans_encode(const int32_t* symbols, const int32_t* indexe
       return DVC_ENOSPC;
     }
     const int32_t idx = indexes[i];
-    DVC_REQUIRE(idx >= 0 && idx < n_cdfs, "dvc_rans_encode: index %d out of range at %lld", idx, (long long)i);
     const int32_t* cdf = cdfs + (int64_t)idx * cdf_stride;
     const int32_t max_value = cdf_sizes[idx] - 2;
     int32_t value = symbols[i] - offsets[idx];
@@ -173,12 +174,35 @@ extern "C" int dvc_rans_decode(const uint8_t* data, int64_t n_bytes, const int32
       f[b] = (uint16_t)s;
     }
   }
+  for (int64_t i = 0; i < n; ++i)
+    DVC_REQUIRE(indexes[i] >= 0 && indexes[i] < n_cdfs, "dvc_rans_decode: index %d out of range at %lld", indexes[i], (long long)i);
+  // the zero symbol of every table (position -offset): one range check decodes it without a table search
+  struct Zero { uint32_t start, freq; int32_t value; };
+  std::vector<Zero> zero((size_t)n_cdfs);
+  for (int32_t c = 0; c < n_cdfs; ++c) {
+    const int32_t* cdf = cdfs + (int64_t)c * cdf_stride;
+    const int64_t pos = -(int64_t)offsets[c];
+    zero[c] = Zero{0, 0, 0};
+    if (pos >= 0 && pos < cdf_sizes[c] - 2) zero[c] = Zero{(uint32_t)cdf[pos], (uint32_t)(cdf[pos + 1] - cdf[pos]), 0};
+  }
   for (int64_t i = 0; i < n; ++i) {
     const int32_t idx = indexes[i];
-    DVC_REQUIRE(idx >= 0 && idx < n_cdfs, "dvc_rans_decode: index %d out of range at %lld", idx, (long long)i);
+    const uint32_t cum = (uint32_t)(rd.x & mask);
+    {
+      const Zero& z = zero[idx];
+      if (cum - z.start < z.freq) {     // (unsigned: also false for cum < start; freq 0 disables the entry)
+        rd.x = (uint64_t)z.freq * (rd.x >> kPrecision) + cum - z.start;
+        rd.renorm();
+        if (!rd.ok) {
+          dvc::set_error("dvc_rans_decode: bitstream exhausted or malformed at symbol %lld", (long long)i);
+          return DVC_EFORMAT;
+        }
+        symbols_out[i] = 0;
+        continue;
+      }
+    }
     const int32_t* cdf = cdfs + (int64_t)idx * cdf_stride;
     const int32_t max_value = cdf_sizes[idx] - 2;
-    const uint32_t cum = (uint32_t)(rd.x & mask);
     // largest s with cdf[s] <= cum: bucket bounds, then bisection inside the bucket
     const uint16_t* f = first.data() + (size_t)idx * (kBuckets + 1) + (cum >> 8);
     int32_t lo = f[0], hi = f[1] + 1;

@@ -102,6 +102,8 @@ def evaluate_sequence(net, frames: Sequence[torch.Tensor], gop: int = 32, intra:
         clamp = lambda t: t.clamp(0, 1)
     ranges = sharding.gop_ranges(len(frames), gop)
     segments, nbytes, sum_psnr, count = [], 0, 0.0, 0
+    if hasattr(net, "decode_lookahead"):
+        net.decode_lookahead = True        # code_gop decodes every frame right after encoding it
     with torch.no_grad():
         for g in sharding.gops_of_rank(len(ranges), rank, world):
             s, e = ranges[g]

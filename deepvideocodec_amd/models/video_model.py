@@ -15,6 +15,7 @@ Differences from the reference that a caller can observe:
     round trip returns, so it is computed on the GPU while the host codes the bytes.
 """
 import math
+import os
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional
 
@@ -32,6 +33,8 @@ from .utils import resize_registered_buffers
 
 Tensor = torch.Tensor
 _POOL = ThreadPoolExecutor(max_workers=6)
+# DVC_DECODE_OVERLAP=0 keeps decode_inter on one stream (for measuring what the overlap buys)
+_DECODE_OVERLAP = os.environ.get("DVC_DECODE_OVERLAP", "1") != "0"
 
 
 class FeatureExtractor(nn.Module):
@@ -172,21 +175,45 @@ class _PendingStrings:
         self._host = None
 
     def start_download(self):
-        self._host = [torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True) for t in self._dev]
+        """Device -> pinned host copies on the current stream, followed by an event: the host can wait for
+        exactly these symbols while later kernels of the frame keep the GPU busy."""
+        self._host = [_pinned_like(t) for t in self._dev]
         for h, d in zip(self._host, self._dev):
             h.copy_(d, non_blocking=True)
+        self._ready = torch.cuda.Event()
+        self._ready.record()
 
     def encode(self) -> Dict:
-        """Call after the stream has been synchronised."""
+        """Waits for the download (not for the rest of the stream) and range-codes the three streams."""
         if self._host is None:
             self.start_download()
-            torch.cuda.current_stream().synchronize()
+        self._ready.synchronize()
         z_sym, y_sym, y_idx = (t.numpy() for t in self._host)
         gc, eb = self.model.gaussian_conditional, self.model.entropy_bottleneck
         f0 = _POOL.submit(gc.compress_symbols, y_sym[0], y_idx[0])
         f1 = _POOL.submit(gc.compress_symbols, y_sym[1], y_idx[1])
         fz = _POOL.submit(eb.compress_symbols, z_sym)
         return {"strings": [f0.result(), f1.result(), fz.result()], "shape": self.z_shape}
+
+
+def _pinned_like(t: Tensor) -> Tensor:
+    return torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+
+
+def _download(t: Tensor) -> np.ndarray:
+    """Device tensor -> numpy through a pinned buffer; waits for this copy only."""
+    h = _pinned_like(t)
+    h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.synchronize()
+    return h.numpy()
+
+
+def _upload(a: np.ndarray, device) -> Tensor:
+    """numpy -> device through a pinned buffer, asynchronous on the current stream."""
+    h = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    return h.to(device, non_blocking=True)
 
 
 class _DualPriorContextModel(CompressionModel):
@@ -266,11 +293,11 @@ class _DualPriorContextModel(CompressionModel):
         z_hat = eb.decompress(strings[2], shape)
         means, scales = self._prior_params(z_hat, y_ref, context)
         idx0 = ops.dual_prior_dec_indexes(scales, 0, C, table)
-        q0 = torch.from_numpy(gc.decompress_symbols(strings[0], idx0.cpu().numpy())).to(dev)
+        q0 = _upload(gc.decompress_symbols(strings[0], _download(idx0)), dev)
         yhat1 = ops.dual_prior_dec_apply(q0, means, 0, C)
         spatial = self.y_spatial_prior((yhat1, means, scales))
         idx1 = ops.dual_prior_dec_indexes(spatial, 1, C, table)
-        q1 = torch.from_numpy(gc.decompress_symbols(strings[1], idx1.cpu().numpy())).to(dev)
+        q1 = _upload(gc.decompress_symbols(strings[1], _download(idx1)), dev)
         return ops.dual_prior_dec_apply(q1, spatial, 1, C, yhat1=yhat1)
 
 
@@ -354,6 +381,8 @@ class DMC(nn.Module):
         self.frame_context_model = FrameContextModel(N, M)
         self.recon_generation_net = ReconGeneration()
         self._initialize_weights()
+        # evaluation loops that decode every frame right after encoding it may set this (see _start_lookahead)
+        self.decode_lookahead = False
 
     def _initialize_weights(self):
         """Xavier-normal(gain sqrt 2) weights, bias 0.01 on every conv (reference: :508-513)."""
@@ -370,11 +399,13 @@ class DMC(nn.Module):
             feature = self.feature_adaptor_P(dpb["feature_ref"])
         return self.feature_extractor(feature)
 
-    def motion_compensation(self, mv, dpb):
+    def motion_compensation(self, mv, dpb, ref_features=None):
+        """reference: video_model.py:497-506.  `ref_features`: the output of multi_scale_feature_extractor(dpb)
+        when the caller has already computed it (it does not depend on the motion)."""
         warpframe = flow_warp(dpb["x_ref"], mv)
         mv2 = bilineardownsacling(mv, 0.5)
         mv3 = bilineardownsacling(mv2, 0.5)
-        ref_feature1, ref_feature2, ref_feature3 = self.multi_scale_feature_extractor(dpb)
+        ref_feature1, ref_feature2, ref_feature3 = ref_features or self.multi_scale_feature_extractor(dpb)
         context1 = flow_warp(ref_feature1, mv)
         context2 = flow_warp(ref_feature2, mv2)
         context3 = flow_warp(ref_feature3, mv3)
@@ -436,8 +467,9 @@ class DMC(nn.Module):
         y = self.contextual_encoder(x_cur, context1, context2, context3)
         _, frame_pending = fcm._compress_device(y, dpb["y_ref"], context3)
         frame_pending.start_download()
-        torch.cuda.current_stream().synchronize()
-        mv_strings = mv_pending.encode()
+        if self.decode_lookahead:
+            self._start_lookahead(dpb)
+        mv_strings = mv_pending.encode()       # waits for the motion symbols only: the GPU is still working
         frame_strings = frame_pending.encode()
         return {
             "strings": {"motion": mv_strings["strings"], "frame": frame_strings["strings"]},
@@ -466,7 +498,6 @@ class DMC(nn.Module):
         frame_pending.start_download()
         x_rec_feature = self.contextual_decoder(y_hat, context2, context3)
         feature, x_rec = self.recon_generation_net(x_rec_feature, context1)
-        torch.cuda.current_stream().synchronize()
         mv_strings = mv_pending.encode()
         frame_strings = frame_pending.encode()
         enc = {
@@ -477,14 +508,58 @@ class DMC(nn.Module):
 
     @torch.no_grad()
     def decode_inter(self, strings, shapes, dpb):
-        """reference: video_model.py:601-614."""
+        """reference: video_model.py:601-614.  The reference features (feature adaptor + extractor, ~5 % of the
+        frame's arithmetic) do not depend on the motion, so they run on a side stream while the host range-decodes
+        the motion symbols -- the decoder's two host round trips per context model otherwise leave the GPU idle."""
+        main = torch.cuda.current_stream()
+        side = self._side_stream(main.device)
+        ref_features = self._take_lookahead(dpb)
+        if ref_features is None and _DECODE_OVERLAP:
+            side.wait_stream(main)                  # the buffer's tensors were produced on the caller's stream
+            with torch.cuda.stream(side):
+                ref_features = self.multi_scale_feature_extractor(dpb)
         y_mv_hat = self.motion_context_model.decompress(strings["motion"], shapes["motion"], dpb["y_mv_ref"])
         mv_hat = self.motion_decoder(y_mv_hat)
-        context1, context2, context3, x_warp = self.motion_compensation(mv_hat, dpb)
+        if ref_features is not None:
+            main.wait_stream(side)
+            for f in ref_features:
+                f.record_stream(main)
+        context1, context2, context3, x_warp = self.motion_compensation(mv_hat, dpb, ref_features)
         y_hat = self.frame_context_model.decompress(strings["frame"], shapes["frame"], dpb["y_ref"], context3)
         x_rec_feature = self.contextual_decoder(y_hat, context2, context3)
         feature, x_rec = self.recon_generation_net(x_rec_feature, context1)
         return x_rec, {"x_ref": x_rec, "feature_ref": feature, "y_ref": y_hat, "y_mv_ref": y_mv_hat}
+
+    def _start_lookahead(self, dpb):
+        """With `decode_lookahead` set (the caller decodes every frame right after encoding it, as the
+        evaluation loop dmc/test.py:186-188 does): queue the decoder's reference-feature extraction for this
+        buffer behind the encoder's kernels, on the side stream, so that it runs while the host range-codes
+        the frame's symbols instead of after decode_inter has been entered.  The decoder's work is unchanged
+        (it does not reuse the encoder's tensors), only started earlier; decode_inter picks the result up when
+        it is called with the same buffer tensors and recomputes otherwise."""
+        import threading
+        main = torch.cuda.current_stream()
+        side = self._side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            feats = self.multi_scale_feature_extractor(dpb)
+        self.__dict__.setdefault("_lookahead", {})[threading.get_ident()] = (dpb["x_ref"], dpb["feature_ref"], feats)
+
+    def _take_lookahead(self, dpb):
+        import threading
+        hit = self.__dict__.get("_lookahead", {}).pop(threading.get_ident(), None)
+        if hit is not None and hit[0] is dpb["x_ref"] and hit[1] is dpb["feature_ref"]:
+            return hit[2]
+        return None
+
+    def _side_stream(self, device):
+        """One helper stream per (host thread, device): GOPs coded from several threads do not share it."""
+        import threading
+        key = (threading.get_ident(), device.index)
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
 
     # ---- housekeeping ---------------------------------------------------------------------------
     def prepare(self):
