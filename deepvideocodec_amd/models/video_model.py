@@ -73,12 +73,14 @@ class MultiScaleContextFusion(nn.Module):
         self.conv1_out = Conv2d(channel_out * 2, channel_out, 3)
         self.res_block1_out = ResBlock(channel_out)
 
-    def forward(self, context1, context2, context3):
+    def forward(self, context1, context2, context3, out2=None, out3=None):
+        """`out2` / `out3` (inference only): where to write the fused half- and quarter-resolution contexts,
+        e.g. the second halves of the concat buffers their consumers read."""
         context3_up = self.res_block3_up(self.conv3_up(context3))
-        context3_new = self.res_block3_out(self.conv3_out(context3), plus=context3)
+        context3_new = self.res_block3_out(self.conv3_out(context3), plus=context3, out=out3)
         cat2 = (context3_up, context2)
         context2_up = self.res_block2_up(self.conv2_up(cat2))
-        context2 = self.res_block2_out(self.conv2_out(cat2), plus=context2)
+        context2 = self.res_block2_out(self.conv2_out(cat2), plus=context2, out=out2)
         context1 = self.res_block1_out(self.conv1_out((context2_up, context1)), plus=context1)
         return context1, context2, context3_new
 
@@ -105,12 +107,10 @@ class ContextualEncoder(nn.Module):
             cat1 = torch.cat((self.conv1((x, context1)), context2), 1)
             cat2 = torch.cat((self.conv2(self.res1(cat1)), context3), 1)
             return self.conv4(self.conv3(self.res2(cat2)))
-        cat1 = torch.empty((n, 2 * N, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        cat1 = _concat_buffer(context2, N)
         self.conv1((x, context1), out=cat1[:, :N])
-        ops.copy_into(context2, cat1[:, N:])
-        cat2 = torch.empty((n, 2 * N, h // 4, w // 4), dtype=torch.float32, device=x.device)
+        cat2 = _concat_buffer(context3, N)
         self.conv2(self.res1(cat1), out=cat2[:, :N])
-        ops.copy_into(context3, cat2[:, N:])
         feature = self.conv3(self.res2(cat2))
         return self.conv4(feature)
 
@@ -136,13 +136,11 @@ class ContextualDecoder(nn.Module):
             feature = self.res1(torch.cat((self.up2(feature), context3), 1))
             feature = self.res2(torch.cat((self.up3(feature), context2), 1))
             return self.up4(feature)
-        cat1 = torch.empty((n, 2 * N, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
+        cat1 = _concat_buffer(context3, N)
         self.up2(feature, out=cat1[:, :N])
-        ops.copy_into(context3, cat1[:, N:])
         feature = self.res1(cat1)
-        cat2 = torch.empty((n, 2 * N, 8 * h, 8 * w), dtype=torch.float32, device=x.device)
+        cat2 = _concat_buffer(context2, N)
         self.up3(feature, out=cat2[:, :N])
-        ops.copy_into(context2, cat2[:, N:])
         feature = self.res2(cat2)
         return self.up4(feature)
 
@@ -162,6 +160,33 @@ class ReconGeneration(nn.Module):
         feature = self.unet_1(feature)
         feature = self.unet_2(feature)
         return feature, self.recon_conv(feature)
+
+
+def _new_concat_context(n, channels, h, w, device):
+    """A (n, 2*channels, h, w) buffer whose second half is handed out as the place for a context tensor: the
+    bottleneck ResBlocks of the contextual encoder / decoder read cat[conv output, context] as ONE tensor (it is
+    also their skip operand), so the context is produced where its consumer needs it instead of being copied."""
+    buf = torch.empty((n, 2 * channels, h, w), dtype=torch.float32, device=device)
+    view = buf[:, channels:]
+    view._dvc_concat = [buf]        # one consumer may claim the buffer's first half
+    return view
+
+
+def _concat_buffer(context: Tensor, channels: int) -> Tensor:
+    """The concat buffer `context` already sits in (second half) if it has one that nobody has claimed yet;
+    otherwise a fresh buffer with `context` copied into its second half."""
+    slot = getattr(context, "_dvc_concat", None)
+    if slot:
+        return slot.pop()
+    n, _, h, w = context.shape
+    buf = torch.empty((n, 2 * channels, h, w), dtype=torch.float32, device=context.device)
+    ops.copy_into(context, buf[:, channels:])
+    return buf
+
+
+def _checkpoint(fn, *args):
+    from torch.utils.checkpoint import checkpoint
+    return checkpoint(fn, *args, use_reentrant=False)
 
 
 # ----------------------------------------------------------------------------------------
@@ -383,6 +408,10 @@ class DMC(nn.Module):
         self._initialize_weights()
         # evaluation loops that decode every frame right after encoding it may set this (see _start_lookahead)
         self.decode_lookahead = False
+        # training: drop the activations of the two largest blocks (reconstruction UNets, context fusion: ~55 %
+        # of the frame's arithmetic and most of its saved tensors) after the forward pass and recompute them
+        # during backward -- trades ~1/3 more forward work for the memory that 7-frame batches of 32 need
+        self.recompute = False
 
     def _initialize_weights(self):
         """Xavier-normal(gain sqrt 2) weights, bias 0.01 on every conv (reference: :508-513)."""
@@ -409,7 +438,17 @@ class DMC(nn.Module):
         context1 = flow_warp(ref_feature1, mv)
         context2 = flow_warp(ref_feature2, mv2)
         context3 = flow_warp(ref_feature3, mv3)
-        context1, context2, context3 = self.context_fusion_net(context1, context2, context3)
+        if torch.is_grad_enabled():
+            if self.recompute:
+                context1, context2, context3 = _checkpoint(self.context_fusion_net, context1, context2, context3)
+            else:
+                context1, context2, context3 = self.context_fusion_net(context1, context2, context3)
+        else:
+            n, c, h, w = context1.shape
+            out2 = _new_concat_context(n, c, h // 2, w // 2, context1.device)
+            out3 = _new_concat_context(n, c, h // 4, w // 4, context1.device)
+            context1, _, _ = self.context_fusion_net(context1, context2, context3, out2=out2, out3=out3)
+            context2, context3 = out2, out3
         return context1, context2, context3, warpframe
 
     # ---- training / evaluation forward ----------------------------------------------------
@@ -446,7 +485,10 @@ class DMC(nn.Module):
         y = self.contextual_encoder(x_cur, context1, context2, context3)
         y_hat, frame_likelihoods = self.frame_context_model(y, dpb["y_ref"], context3)
         x_rec_feature = self.contextual_decoder(y_hat, context2, context3)
-        feature, x_rec = self.recon_generation_net(x_rec_feature, context1)
+        if self.recompute and torch.is_grad_enabled():
+            feature, x_rec = _checkpoint(self.recon_generation_net, x_rec_feature, context1)
+        else:
+            feature, x_rec = self.recon_generation_net(x_rec_feature, context1)
         return (x_rec, {"motion": mv_likelihoods, "frame": frame_likelihoods},
                 {"y_mv_ref": y_mv_hat, "y_ref": y_hat, "feature_ref": feature, "x_ref": x_rec})
 

@@ -52,13 +52,16 @@ def _oracle_with_noise(sd, draw):
     return ent
 
 
-@pytest.mark.timeout(600)
-def test_training_step_gradients_match_oracle(seeded_sd):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_frames", [3, 7])
+def test_training_step_gradients_match_oracle(seeded_sd, n_frames):
+    """T = 3 is the reference's launch script (dmc/train.sh:9), T = 7 a whole Vimeo septuplet: the gradient
+    then flows back through six P frames of decoded-picture-buffer recurrence."""
     from deepvideocodec_amd.models import DMC
     from deepvideocodec_amd.models import entropy_models as EM
     from deepvideocodec_amd.testing import synthetic_gop
-    frames = synthetic_gop(3, 64, 64, seed=5)
-    n_pix = 64 * 64 * 2
+    frames = synthetic_gop(n_frames, 64, 64, seed=5)
+    n_pix = 64 * 64 * (n_frames - 1)
 
     # ---- oracle (CPU autograd)
     sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "entropy_bottleneck" not in k and
@@ -87,9 +90,9 @@ def test_training_step_gradients_match_oracle(seeded_sd):
     sum(aux).backward()
 
     assert abs(loss_g.item() - loss_o.item()) <= 2e-4 * abs(loss_o.item()), (loss_g.item(), loss_o.item())
-    for i in range(2):
+    for i in range(n_frames - 1):
         d = (out_g["x_hat"][i].detach().cpu() - out_o["x_hat"][i].detach()).abs().max().item()
-        assert d < 2e-4, (i, d)
+        assert d < 2e-4 * (1 + i), (i, d)
 
     # Per-tensor comparison.  A handful of activations sit within rounding noise of a LeakyReLU
     # kink or a rounding tie on one side only, which perturbs the gradients that pass through them,
@@ -236,3 +239,71 @@ def test_fit_epoch_loop_and_resume(seeded_sd, tmp_path):
     # the resumed model evaluates to the same loss
     crit = TR.RateDistortionLoss(lmbda=2048.0, return_details=True)
     assert TR.test_epoch(0, loader((3,)), None, net2, crit) == pytest.approx(res["test_loss"], rel=1e-6)
+
+
+@pytest.mark.timeout(300)
+def test_train_step_at_the_stated_workload(seeded_sd):
+    """BASELINE configs[2]: one training step on a batch of 32 samples of 256x256, T = 3 (dmc/train.sh:3-9:
+    lambda 2048, Adam 1e-4, clip 1.0), joint stage: finite losses, every main parameter moves, and the step
+    takes seconds, not minutes."""
+    import time
+    from deepvideocodec_amd import train as TR
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_sd)
+    net = net.cuda().train()
+    crit = TR.RateDistortionLoss(lmbda=2048.0)
+    opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
+    frames = [f.cuda() for f in synthetic_gop(3, 256, 256, seed=12, batch=32)]
+    main = {n: p for n, p in net.named_parameters() if not n.endswith(".quantiles")}
+    before = {n: p.detach().clone() for n, p in main.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = TR.train_step(net, crit, frames, opt, aux_opt, clip_max_norm=1.0, epoch=45)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"batch 32, 256x256, T=3: {dt:.2f} s (first step, includes weight packing), {stats}, "
+          f"{torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB peak")
+    assert all(math.isfinite(v) for v in stats.values()), stats
+    assert dt < 60.0, dt
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in main.items())
+    assert moved == len(main), (moved, len(main))
+
+
+def test_recompute_gives_identical_gradients(seeded_sd):
+    """DMC.recompute (activations of the reconstruction / fusion blocks recomputed in backward): same loss, the
+    same gradients up to summation order (the order in which autograd accumulates the contributions to a shared
+    tensor changes, and the warp adjoint adds with float atomics), half the memory held between forward and
+    backward."""
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.models import entropy_models as EM
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = [f.cuda() for f in synthetic_gop(4, 128, 128, seed=14, batch=2)]
+    n_pix = 128 * 128 * 3 * 2
+    results = []
+    for recompute in (False, True):
+        net = DMC()
+        net.load_state_dict(seeded_sd)
+        net = net.cuda().train()
+        net.recompute = recompute
+        _, draw = _shared_noise(9)
+        EM._noise_hook = lambda shape, device: draw(shape).to(device)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        try:
+            loss = _loss(net(frames), frames, n_pix)
+            held = torch.cuda.memory_allocated() - base
+            loss.backward()
+        finally:
+            EM._noise_hook = None
+        results.append((loss.item(), held, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+        del net, loss
+    (l0, m0, g0), (l1, m1, g1) = results
+    print(f"held between forward and backward: {m0 / 2 ** 20:.0f} MiB -> {m1 / 2 ** 20:.0f} MiB with recompute")
+    assert l0 == l1 and g0.keys() == g1.keys()
+    worst = max(float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-20) for k in g0)
+    print(f"largest gradient difference relative to the tensor's largest entry: {worst:.2e}")
+    assert worst < 1e-4, worst
+    assert m1 < 0.75 * m0, (m0, m1)
