@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <type_traits>
+#include <utility>
 
 #include "dvc_common.h"
 #include "conv_args.h"
@@ -32,6 +33,27 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the
+// body (register arrays indexed by it are never addressed dynamically, whatever the unroller decides)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// One LDS dword at (per-lane byte address + immediate): issues the read and returns at once -- the value is valid
+// only behind an s_waitcnt lgkmcnt that covers it, which the caller places (the compiler does not track this read).
+template <int OFFSET_BYTES>
+__device__ __forceinline__ float lds_read_imm(unsigned addr) {
+  static_assert(OFFSET_BYTES >= 0 && OFFSET_BYTES < 65536, "DS instructions carry a 16-bit offset");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET_BYTES));
+  return v;
+}
 
 // input channels staged per K-chunk (even)
 constexpr int chunk_of(int ks, int s) { return dvc::conv_chunk_of(ks, s); }
@@ -106,6 +128,19 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #else
 #define DVC_STAMP(k)
 #endif
+// -DDVC_STAMP_CHUNKS (with DVC_CONV_STAMPS): shader-clock stamps of the phases of K chunks 2 and 3 in slots 8..15
+// instead of the epilogue's per-tile stamps
+#if defined(DVC_CONV_STAMPS) && defined(DVC_STAMP_CHUNKS)
+#define DVC_CSTAMP(cond, slot)                                                                                \
+  do {                                                                                                        \
+    if (g_conv_stamps != nullptr && threadIdx.x == 0 && (cond)) {                                             \
+      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      g_conv_stamps[wg_ * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
+    }                                                                                                         \
+  } while (0)
+#else
+#define DVC_CSTAMP(cond, slot)
+#endif
 
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
@@ -175,7 +210,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   // for the next tap (10 % of the K loop for a wave alone on its SIMD).
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)SLAB), 0x00020000);
-  auto dma_weights = [&](int chunk, int buf) {
+  auto dma_weights = [&](int chunk, int buf) __attribute__((always_inline)) {
     float* dst = w_s + buf * SLAB;
     const unsigned soff = 4u * (unsigned)chunk * (unsigned)SLAB;
 #pragma unroll
@@ -213,7 +248,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   // the per-lane offsets) -- a couple of scalar instructions per channel and no branches, so the
   // loads can be scheduled between the MFMAs of the current chunk.  Otherwise (a chunk straddling two
   // concatenated sources, or running past the last channel): one descriptor per channel.
-  auto prefetch_input = [&](int c0) {
+  // State of a chunk's input fetch: the buffer descriptor base and channel stride of the common case.
+  struct Fetch { unsigned lo, hi, cs4, soff0; bool fast; };
+  // Starts the fetch of chunk c0: works out the common-case state, or (chunk straddling sources / running past
+  // the last channel) issues all of the chunk's loads with one descriptor per channel and returns fast = false.
+  auto prefetch_begin = [&](int c0) __attribute__((always_inline)) -> Fetch {
     const int cl = c0 + CK - 1;
     const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
     const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
@@ -229,25 +268,16 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
       const unsigned long long base = b0 + ((b1 - b0) & m0) + ((b2 - b1) & m1) + ((b3 - b2) & m2);
       const long long cs = cs0 + ((cs1 - cs0) & (long long)m0) + ((cs2 - cs1) & (long long)m1) + ((cs3 - cs2) & (long long)m2);
       const int first = (e0 & (int)m0) + ((e1 - e0) & (int)m1) + ((e2 - e1) & (int)m2);
-      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-      const unsigned cs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)cs);
-      const unsigned soff0 = __builtin_amdgcn_readfirstlane((unsigned)(c0 - first) * cs4);
-#pragma unroll
-      for (int c = 0; c < CK; ++c) {
-        // the range check compares the per-lane offset with (records - scalar offset): records end
-        // with this channel's plane
-        const unsigned soff = soff0 + (unsigned)c * cs4;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, soff + plane_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < IN_PT; ++j)
-          rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
-      }
-      return;
+      Fetch f;
+      f.lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+      f.hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+      f.cs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)cs);
+      f.soff0 = __builtin_amdgcn_readfirstlane((unsigned)(c0 - first) * f.cs4);
+      f.fast = true;
+      return f;
     }
-#pragma unroll
-    for (int c = 0; c < CK; ++c) {
+    static_for<CK>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
       const int ci = c0 + c;
       const bool have = ci < cin;
       unsigned long long pl;
@@ -272,10 +302,43 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 #pragma unroll
       for (int j = 0; j < IN_PT; ++j)
         rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], 0, 0));
+    });
+    return Fetch{0u, 0u, 0u, 0u, false};
+  };
+  // Common case (the chunk lies inside one source and inside cin): one buffer descriptor on the source's sample,
+  // the channel as the scalar offset operand of the load (not part of the range check, which keeps working per
+  // plane through the per-lane offsets) -- a couple of scalar instructions per channel and no branches, so a
+  // channel's loads fit between two MFMAs of the current chunk.
+  auto prefetch_channel = [&](const Fetch& f, int c) __attribute__((always_inline)) {
+    // the range check compares the per-lane offset with (records - scalar offset): records end
+    // with this channel's plane
+    const unsigned soff = f.soff0 + (unsigned)c * f.cs4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)f.hi << 32) | f.lo), 0, soff + plane_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < IN_PT; ++j)
+      rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
+  };
+  // One K-chunk of input, global -> registers, all at once.
+  auto prefetch_input = [&](int c0) __attribute__((always_inline)) {
+    const Fetch f = prefetch_begin(c0);
+    if (f.fast) {   // workgroup-uniform
+      static_for<CK>([&](auto cc) __attribute__((always_inline)) { prefetch_channel(f, decltype(cc)::value); });
     }
   };
 
-  auto commit_input = [&](int buf) {
+  // registers -> LDS, one channel of the chunk (fp32 layout [channel][element])
+  auto commit_channel = [&](int buf, int c) __attribute__((always_inline)) {
+    float* dst = in_s + buf * IN_BUF + tid;
+    if (in_act) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < IN_PT; ++j) rin[c][j] = dvc::leaky(rin[c][j], in_slope);
+    }
+#pragma unroll
+    for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
+      if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
+  };
+  auto commit_input = [&](int buf) __attribute__((always_inline)) {
     float* dst = in_s + buf * IN_BUF + tid;
     if (in_act) {   // wave-uniform
 #pragma unroll
@@ -336,10 +399,24 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 
   for (int k = 0; k < nchunks; ++k) {
     const int cur = NBUF == 2 ? (k & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
-    if (k + 1 < nchunks) {   // chunk k+1 in flight during the MFMA phase
+    DVC_CSTAMP(k == 2, 8);
+    DVC_CSTAMP(k == 3, 13);
+    const bool more = k + 1 < nchunks;
+    // fp32 mode with enough tap groups per chunk: the next chunk's loads are issued one channel per tap group
+    // behind the first CK groups' MFMAs and committed to LDS one channel per group behind the last CK groups'
+    // (a workgroup that has its CU's matrix pipes to itself would otherwise leave them idle for that long)
+    constexpr int T_GROUPS = (CK / 2) * TAPS;
+    constexpr bool SPREAD = BF == 0 && T_GROUPS >= 2 * CK && MT * NT >= 2;
+    // (with fewer than four MFMAs per tap group a chunk is over before its loads have come back: an early wait
+    // inside the loop would hold up the MFMAs behind it, so those variants commit after the loop as before)
+    constexpr bool SPREAD_COMMIT = SPREAD && NBUF == 2 && MT * NT >= 4;
+    Fetch nextf{0u, 0u, 0u, 0u, false};
+    if (more) {   // chunk k+1 in flight during the MFMA phase
       if (NBUF == 2) dma_weights(k + 1, nxt);
-      prefetch_input((k + 1) * CK);
+      if constexpr (SPREAD) nextf = prefetch_begin((k + 1) * CK);
+      else prefetch_input((k + 1) * CK);
     }
+    DVC_CSTAMP(k == 2, 9);
     if constexpr (BF) {
       using V8 = typename Half16<G::F16>::V8;
       const V8* bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
@@ -390,40 +467,86 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
         }
       }
     } else {
-      const float* bbase = in_s + cur * IN_BUF + b_lane;
-      const float* abase = w_s + cur * SLAB + a_lane;
+      // Operand reads as explicit ds_read_b32 with 16-bit immediate offsets off two per-lane base addresses, and
+      // explicit wait counts.  Left to the compiler the reads are paired into ds_read2_b32, whose 8-bit offsets
+      // need a fresh base register every few taps -- and a VALU instruction between two MFMA groups of one wave
+      // waits for the matrix pipe to drain: about 40 of every 512 cycles when the wave has its SIMD to itself.
+      // The compiler does not know these reads are asynchronous: every value is consumed only behind the
+      // s_waitcnt that covers it, and the sched_barriers keep the MFMAs on their side of that wait.
+      const unsigned b_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(in_s + cur * IN_BUF + b_lane);
+      const unsigned a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)(w_s + cur * SLAB + a_lane);
       constexpr int T = (CK / 2) * TAPS;
       float av[2][MT], bv[2][NT];
-      auto fetch = [&](int t, int slot) {
-        const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
-  #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[slot][mt] = abase[(2 * cp * TAPS + tap) * CBP + mt * 32];
-  #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[slot][nt] = bbase[2 * cp * CHS + (nt * SL + ky) * IW + kx];
+      auto fetch = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, slot = t & 1;
+        constexpr int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
+        static_for<MT>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int mt = decltype(mc)::value;
+          av[slot][mt] = lds_read_imm<4 * ((2 * cp * TAPS + tap) * CBP + mt * 32)>(a_addr);
+        });
+        static_for<NT>([&](auto nc) __attribute__((always_inline)) {
+          constexpr int nt = decltype(nc)::value;
+          bv[slot][nt] = lds_read_imm<4 * (2 * cp * CHS + (nt * SL + ky) * IW + kx)>(b_addr);
+        });
       };
-      fetch(0, 0);
+      static_assert(4 * (CK * TAPS * CBP + 32) < 65536 && 4 * (CK * CHS) < 65536, "operand offsets exceed the DS offset field");
+      constexpr int kWaitAllButNext = 0xC07F | ((MT + NT) << 8);   // s_waitcnt lgkmcnt(MT + NT): the reads just issued may stay in flight
+      constexpr int kWaitAll = 0xC07F;                             // s_waitcnt lgkmcnt(0)
+      if constexpr (MT * NT == 1) {
+        // one MFMA per tap: nothing to hide a wait behind, the compiler's own pairing and scheduling of the reads
+        // is the faster form here
+        const float* bbase = in_s + cur * IN_BUF + b_lane;
+        const float* abase = w_s + cur * SLAB + a_lane;
+        auto fetch1 = [&](int t, int slot) __attribute__((always_inline)) {
+          const int cp = t / TAPS, tap = t - cp * TAPS, ky = tap / KS, kx = tap - ky * KS;
+          av[slot][0] = abase[(2 * cp * TAPS + tap) * CBP];
+          bv[slot][0] = bbase[2 * cp * CHS + ky * IW + kx];
+        };
+        fetch1(0, 0);
   #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fetch(t + 1, (t + 1) & 1);   // operands of the next tap while this one multiplies
-  #ifndef DVC_NO_SCHED_PIN
-        __builtin_amdgcn_sched_barrier(0);          // keep those LDS reads ahead of this tap's MFMAs
-  #endif
+        for (int t = 0; t < T; ++t) {
+          if (t + 1 < T) fetch1(t + 1, (t + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][0], bv[t & 1][0], acc[0][0], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+      fetch(std::integral_constant<int, 0>{});
+      static_for<T>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t == 10) DVC_CSTAMP(k == 3, 14);
+        if constexpr (t == 26) DVC_CSTAMP(k == 3, 15);
+        if constexpr (t + 1 < T) {   // operands of the next tap while this one multiplies
+          fetch(std::integral_constant<int, t + 1>{});
+          __builtin_amdgcn_s_waitcnt(kWaitAllButNext);
+        } else {
+          __builtin_amdgcn_s_waitcnt(kWaitAll);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // the MFMAs stay behind the wait that covers their operands
   #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-  #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
-  #ifndef DVC_NO_SCHED_PIN
+        for (int i = 0; i < MT * NT; ++i) {
+          const int mt = i / NT, nt = i - mt * NT;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+          if constexpr (SPREAD) {
+            if (i == 0) {   // behind the group's first MFMA: the pipe is busy for the next 64 cycles anyway
+              if constexpr (t < CK) { if (nextf.fast) prefetch_channel(nextf, t); }
+              if constexpr (SPREAD_COMMIT && t >= T - CK) { if (more) commit_channel(nxt, t - (T - CK)); }
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
-  #endif
+      });
       }
     }
+    DVC_CSTAMP(k == 2, 10);
     if (NBUF == 1) {   // single buffers: everyone must be done reading before the next chunk lands
       __syncthreads();
-      if (k + 1 < nchunks) dma_weights(k + 1, 0);
+      if (more) dma_weights(k + 1, 0);
     }
-    if (k + 1 < nchunks) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
-    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): the DMA pieces have landed (a form the compiler's wait-count tracking sees) */   // this wave's DMA pieces have landed in LDS
+    if (more && !SPREAD_COMMIT) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
+    DVC_CSTAMP(k == 2, 11);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA pieces have landed in LDS (a form the compiler's wait-count tracking sees) */
+    DVC_CSTAMP(k == 2, 12);
     __syncthreads();
   }
 
@@ -529,7 +652,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
             }
             if (ok[q]) *reinterpret_cast<float4*>(out_n + chs[q] * a.ocs + pix[q]) = v;
           }
+#ifndef DVC_STAMP_CHUNKS
           DVC_STAMP(8 + ((mt * NT + nt) & 7));
+#endif
         }
       }
     };
@@ -766,6 +891,9 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
 inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
   const long long cblocks = (a.cout + 32 * mt - 1) / (32 * mt);
   const long long tx = (a.wo + 31) / 32;
+#ifdef DVC_CONV_STAMPS
+  if (const char* f = getenv("DVC_CONV_FORCE_NT")) return atoi(f);   // diagnostic build: e.g. one workgroup per CU
+#endif
   for (int nt = max_nt; nt > 1; nt >>= 1) {
     const long long blocks = (long long)((a.ho + 4 * nt - 1) / (4 * nt)) * tx * cblocks * batch;
     if (blocks >= 480) return nt;   // (within a few percent of two workgroups per CU counts)

@@ -28,8 +28,12 @@ def main():
     b = torch.randn(cout, device="cuda")
     packed = ops.pack_conv_weight(wt, 1)
     out = ops.conv2d(x, wt, b, packed=packed)
-    for _ in range(3):
-        ops.conv2d(x, wt, b, packed=packed, out=out)
+    import time
+    t_end = time.time() + 2.0   # two seconds of back-to-back launches: the clock has ramped up from idle by then
+    while time.time() < t_end:
+        for _ in range(20):
+            ops.conv2d(x, wt, b, packed=packed, out=out)
+        torch.cuda.synchronize()
     n_wg = 1 << 16
     buf = torch.zeros(n_wg * 16, dtype=torch.int64, device="cuda")
     assert lib.dvc_debug_conv_stamps(buf.data_ptr()) == 0
@@ -55,7 +59,17 @@ def main():
           f"{(t[:, 1] - t[:, 0]).mean():.2f}, K loop {(t[:, 2] - t[:, 1]).mean():.2f}, epilogue {(t[:, 3] - t[:, 2]).mean():.2f}; "
           f"clock {np.median(cyc / np.maximum(dur, 1e-9)) / 1e3:.2f} GHz")
     tiles = st[:, 8:16].astype(np.float64) * 0.01 - t0
-    if (st[:, 8:16] != 0).all():
+    if os.environ.get("DVC_STAMP_CHUNKS"):
+        # library built with -DDVC_STAMP_CHUNKS: slots 8..15 are shader-clock stamps inside K chunks 2 and 3
+        c = st[:, 8:16].astype(np.float64)
+        names = ["start the next chunk's loads", "tap loop (MFMAs)", "commit rest of next chunk to LDS", "wait for DMA",
+                 "barrier", "chunk 3: start .. tap group 10", "chunk 3: tap groups 10..25, per group"]
+        segs = [c[:, 1] - c[:, 0], c[:, 2] - c[:, 1], c[:, 3] - c[:, 2], c[:, 4] - c[:, 3], c[:, 5] - c[:, 4],
+                c[:, 6] - c[:, 5], (c[:, 7] - c[:, 6]) / 16.0]
+        print("K chunk phases of wave 0, shader cycles (mean / median / p90):")
+        for nm, sg in zip(names, segs):
+            print(f"  {nm:34s} {sg.mean():9.0f} {np.median(sg):9.0f} {np.percentile(sg, 90):9.0f}")
+    elif (st[:, 8:16] != 0).all():
         steps = np.diff(np.concatenate([t[:, 2:3], tiles], axis=1), axis=1)
         print("epilogue, per output tile of wave 0 (us, mean):", steps.mean(axis=0).round(2), "clock in K loop n/a")
     start_spread = np.sort(t[:, 0])

@@ -6,10 +6,16 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDSREADS: 0 = operands stay in registers, 1 = re-read from LDS per group (low-entropy values),
+// 2 = re-read from LDS, full-entropy mantissas and mixed signs (the switching activity of real activations)
 template <int LDSREADS>
 __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk, int iters) {
   __shared__ float lds[8192];
-  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = (float)((i * 7) & 31) * 0.01f;
+  for (int i = threadIdx.x; i < 8192; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    lds[i] = LDSREADS == 2 ? ((int)(h & 0xFFFFFF) - 0x800000) * (1.0f / 0x800000) : (float)((i * 7) & 31) * 0.01f;
+  }
   __syncthreads();
   f32x16 acc[8];
   for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
@@ -50,7 +56,7 @@ void run(const char* name, int blocks, int iters) {
   hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
   double cyc = 0, rt = 0; for (int b = 0; b < blocks; ++b) { cyc += h[2 * b]; rt += h[2 * b + 1]; }
   const double flops = (double)blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 2;
-  printf("%-34s blocks %4d: %8.1f us  %6.1f TFLOP/s  clock %.3f GHz  cycles/MFMA/wave %.1f\n", name, blocks, ms * 1e3,
+  printf("%-50s blocks %4d: %8.1f us  %6.1f TFLOP/s  clock %.3f GHz  cycles/MFMA/wave %.1f\n", name, blocks, ms * 1e3,
          flops / ms / 1e9, cyc / rt * 0.1, (cyc / blocks) / (iters * 8.0));
   hipFree(out); hipFree(clk);
 }
@@ -62,5 +68,8 @@ int main() {
   run<1>("MFMA + 6 ds_read_b32, 1 wave/SIMD", 256, iters);
   run<1>("MFMA + 6 ds_read_b32, 2 waves/SIMD", 512, iters);
   run<0>("bare MFMA, 2 waves/SIMD, 8 rounds", 4096, iters / 4);
+  run<2>("MFMA + 6 ds_read_b32 of random data, 1 wave/SIMD", 256, iters);
+  run<2>("MFMA + 6 ds_read_b32 of random data, 2 waves/SIMD", 512, iters);
+  run<2>("same, 2 waves/SIMD, 8 rounds", 4096, iters / 4);
   return 0;
 }

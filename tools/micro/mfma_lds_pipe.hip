@@ -38,6 +38,34 @@ __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk,
             acc[m * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][m], bv[t & 1][n], acc[m * 4 + n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+    } else if (MODE == 2 || MODE == 3) {
+      // MODE 2: the same reads as three ds_read2_b32 (what the compiler makes of them); MODE 3: additionally a
+      // VALU add producing the address of the A reads every tap (offsets beyond the 8-bit range)
+      float2 a2[2], b01[2], b23[2];
+#define RD2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+      unsigned abase = lbase;
+#define FETCH2(t, s)                                                                 \
+  if (MODE == 3) asm volatile("v_add_u32 %0, %1, %2" : "=v"(abase) : "v"(lbase), "v"((unsigned)(((t) & 3) * 256)));  \
+  RD2(a2[s], abase, 0, 32); RD2(b01[s], lbase, 64 + ((t) & 15), 98 + ((t) & 15)); RD2(b23[s], lbase, 132 + ((t) & 15), 166 + ((t) & 15))
+      FETCH2(0, 0);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t + 1 < TAPS) {
+          if ((t + 1) & 1) { FETCH2(t + 1, 1); } else { FETCH2(t + 1, 0); }
+          asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float am[2] = {a2[t & 1].x, a2[t & 1].y};
+        const float bn[4] = {b01[t & 1].x, b01[t & 1].y, b23[t & 1].x, b23[t & 1].y};
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[m], bn[n], acc[m * 4 + n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
 #define RD(dst, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(lbase), "n"(off))
 #define FETCH(t, s)                                                        \
@@ -95,5 +123,7 @@ int main() {
   run<0>("compiler-scheduled pipeline, 2 waves/SIMD", 512, iters);
   run<1>("asm reads + counted waits, 1 wave/SIMD", 256, iters);
   run<1>("asm reads + counted waits, 2 waves/SIMD", 512, iters);
+  run<2>("asm ds_read2 + counted waits, 1 wave/SIMD", 256, iters);
+  run<3>("asm ds_read2 + VALU address, 1 wave/SIMD", 256, iters);
   return 0;
 }
