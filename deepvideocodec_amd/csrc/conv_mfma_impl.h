@@ -14,6 +14,7 @@ namespace {
 using dvc::ConvArgs;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -53,6 +54,12 @@ __device__ __forceinline__ float lds_read_imm(unsigned addr) {
   float v;
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET_BYTES));
   return v;
+}
+
+template <int OFFSET_BYTES>
+__device__ __forceinline__ void lds_write_imm(unsigned addr, float v) {
+  static_assert(OFFSET_BYTES >= 0 && OFFSET_BYTES < 65536, "DS instructions carry a 16-bit offset");
+  asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFFSET_BYTES) : "memory");
 }
 
 // input channels staged per K-chunk (even)
@@ -327,16 +334,21 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     }
   };
 
-  // registers -> LDS, one channel of the chunk (fp32 layout [channel][element])
-  auto commit_channel = [&](int buf, int c) __attribute__((always_inline)) {
-    float* dst = in_s + buf * IN_BUF + tid;
+  // registers -> LDS, one channel of the chunk (fp32 layout [channel][element]), as explicit ds_write_b32 with
+  // immediate offsets off the per-lane byte address `dst_addr` of the buffer: no address arithmetic (VALU) between
+  // the MFMAs this is issued behind.  The compiler does not track these writes: the chunk's closing s_waitcnt
+  // covers them (lgkmcnt(0) before the barrier).
+  auto commit_channel = [&](unsigned dst_addr, auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
     if (in_act) {   // wave-uniform
 #pragma unroll
       for (int j = 0; j < IN_PT; ++j) rin[c][j] = dvc::leaky(rin[c][j], in_slope);
     }
-#pragma unroll
-    for (int j = 0; j < IN_PT; ++j)   // only the last slice of a channel can run past its end
-      if (256 * (j + 1) <= CHS || tid + 256 * j < CHS) dst[c * CHS + 256 * j] = rin[c][j];
+    static_for<IN_PT>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if (256 * (j + 1) <= CHS || tid + 256 * j < CHS)   // only the last slice of a channel can run past its end
+        lds_write_imm<4 * (c * CHS + 256 * j)>(dst_addr, rin[c][j]);
+    });
   };
   auto commit_input = [&](int buf) __attribute__((always_inline)) {
     float* dst = in_s + buf * IN_BUF + tid;
@@ -411,11 +423,16 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     // inside the loop would hold up the MFMAs behind it, so those variants commit after the loop as before)
     constexpr bool SPREAD_COMMIT = SPREAD && NBUF == 2 && MT * NT >= 4;
     Fetch nextf{0u, 0u, 0u, 0u, false};
-    if (more) {   // chunk k+1 in flight during the MFMA phase
-      if (NBUF == 2) dma_weights(k + 1, nxt);
-      if constexpr (SPREAD) nextf = prefetch_begin((k + 1) * CK);
-      else prefetch_input((k + 1) * CK);
-    }
+    auto start_next_chunk = [&]() __attribute__((always_inline)) {   // chunk k+1 in flight during the MFMA phase
+      if (more) {
+        if (NBUF == 2) dma_weights(k + 1, nxt);
+        if constexpr (SPREAD) nextf = prefetch_begin((k + 1) * CK);
+        else prefetch_input((k + 1) * CK);
+      }
+    };
+    if constexpr (!SPREAD) start_next_chunk();   // (spread: behind the first MFMA of the chunk, see below)
+    unsigned commit_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(in_s + nxt * IN_BUF + tid);
+    asm volatile("" : "+v"(commit_addr));   // one register for the whole chunk, not re-derived at every use
     DVC_CSTAMP(k == 2, 9);
     if constexpr (BF) {
       using V8 = typename Half16<G::F16>::V8;
@@ -529,8 +546,11 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mt], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
           if constexpr (SPREAD) {
             if (i == 0) {   // behind the group's first MFMA: the pipe is busy for the next 64 cycles anyway
+              if constexpr (t == 0) start_next_chunk();
               if constexpr (t < CK) { if (nextf.fast) prefetch_channel(nextf, t); }
-              if constexpr (SPREAD_COMMIT && t >= T - CK) { if (more) commit_channel(nxt, t - (T - CK)); }
+              if constexpr (SPREAD_COMMIT && t >= T - CK) {
+                if (more) commit_channel(commit_addr, std::integral_constant<int, t - (T - CK)>{});
+              }
             }
           }
         }
@@ -545,7 +565,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     }
     if (more && !SPREAD_COMMIT) commit_input(nxt);   // (two buffers: nxt was last read before the previous barrier)
     DVC_CSTAMP(k == 2, 11);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0): this wave's DMA pieces have landed in LDS (a form the compiler's wait-count tracking sees) */
+    __builtin_amdgcn_s_waitcnt(0x0070);   /* vmcnt(0) lgkmcnt(0): this wave's DMA pieces and LDS writes have landed (a form the compiler's wait-count tracking sees) */
     DVC_CSTAMP(k == 2, 12);
     __syncthreads();
   }
@@ -731,10 +751,12 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
             for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)];
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[mt][nt][r] + bias_r[r];
+          for (int r = 0; r < 16; r += 2) {   // two values per instruction (v_pk_add_f32, v_pk_mul_f32)
+            const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
+            const f32x2 sv = v * out_slope;
             // LeakyReLU / ReLU / identity (slope 1) as max(v, v * slope): equal to the select for 0 <= slope <= 1
-            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v, v * out_slope);
+            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
+            tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
           }
         }
         if (i > 0) finish((i - 1) / NT, (i - 1) % NT);
