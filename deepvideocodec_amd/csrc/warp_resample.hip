@@ -59,6 +59,11 @@ __device__ __forceinline__ float bilin_fetch(const float* plane, const Bilin& b)
   return plane[b.o_nw] * b.nw + plane[b.o_ne] * b.ne + plane[b.o_sw] * b.sw + plane[b.o_se] * b.se;
 }
 
+// (Measured and not kept: unrolling the channel loop, or a strip of rows per wave, leaves the time unchanged --
+// the gather is bound by vector-cache accesses, about one per cycle and CU, not by latency.  Fetching the west /
+// east pair as one 8-byte load at 4-byte alignment was 1.28x faster alone, but under concurrent kernels from other
+// streams such misaligned 8-byte loads returned wrong data for whole 16-lane groups in a few percent of launches:
+// every multi-dword access in this library is naturally aligned.)
 __global__ __launch_bounds__(256) void flow_warp_kernel(Src src, Src flow, Dst out, int batch, int h, int w) {
   const long long hw = (long long)h * w, total = hw * batch;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -217,17 +222,47 @@ __device__ __forceinline__ float block_sum_256(float v, float* lds4) {
   return r;
 }
 
+// VEC: plane bases are 16-byte aligned (slices are whole float4s apart): 16-byte loads, four independent
+// accumulators per thread.  The summation order is fixed either way.
+template <bool VEC>
 __global__ __launch_bounds__(256) void plane_partial_sum_kernel(Src x, int h, int w, float* partial) {
   __shared__ float red[4];
   const int slice = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
   const long long hw = (long long)h * w;
-  const long long per = (hw + SE_SLICES - 1) / SE_SLICES;
-  const long long b = slice * per, e = b + per < hw ? b + per : hw;
+  const long long per = ((hw + SE_SLICES - 1) / SE_SLICES + 3) & ~3LL;
+  const long long b = slice * per < hw ? slice * per : hw, e = b + per < hw ? b + per : hw;
   const float* p = x.p + n * x.bs + c * x.cs;
   float s = 0.f;
-  for (long long i = b + threadIdx.x; i < e; i += 256) s += p[i];
+  if constexpr (VEC) {
+    const float4* p4 = reinterpret_cast<const float4*>(p + b);
+    const int n4 = (int)((e - b) >> 2);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+      const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+      a0 += (v0.x + v0.y) + (v0.z + v0.w);
+      a1 += (v1.x + v1.y) + (v1.z + v1.w);
+      a2 += (v2.x + v2.y) + (v2.z + v2.w);
+      a3 += (v3.x + v3.y) + (v3.z + v3.w);
+    }
+    for (; i < n4; i += 256) {
+      const float4 v0 = p4[i];
+      a0 += (v0.x + v0.y) + (v0.z + v0.w);
+    }
+    s = (a0 + a1) + (a2 + a3);
+    for (long long j = b + 4LL * n4 + threadIdx.x; j < e; j += 256) s += p[j];   // (last slice only: < 4 elements)
+  } else {
+    for (long long i = b + threadIdx.x; i < e; i += 256) s += p[i];
+  }
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) partial[((long long)n * x.c + c) * SE_SLICES + slice] = s;
+}
+
+void launch_plane_partial_sums(const DvcSrc* x, int batch, int h, int w, float* partial, hipStream_t st) {
+  const bool vec = reinterpret_cast<uintptr_t>(x->ptr) % 16 == 0 && x->batch_stride % 4 == 0 && x->chan_stride % 4 == 0;
+  const dim3 grid(SE_SLICES, x->channels, batch);
+  if (vec) hipLaunchKernelGGL(plane_partial_sum_kernel<true>, grid, dim3(256), 0, st, mk(x), h, w, partial);
+  else hipLaunchKernelGGL(plane_partial_sum_kernel<false>, grid, dim3(256), 0, st, mk(x), h, w, partial);
 }
 
 // one block per n: mean -> fc1 -> relu -> fc2 -> sigmoid
@@ -344,8 +379,7 @@ extern "C" int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w,
   DVC_CHECK_SRC(x, h, w, "dvc_se_gate");
   DVC_REQUIRE(x->channels <= 256 && hidden >= 1 && hidden <= 64, "dvc_se_gate: channels<=256, hidden<=64 required");
   DVC_REQUIRE(fc1 && fc2 && partial && gate, "dvc_se_gate: null pointer");
-  hipLaunchKernelGGL(plane_partial_sum_kernel, dim3(SE_SLICES, x->channels, batch), dim3(256), 0, (hipStream_t)stream,
-                     mk(x), h, w, partial);
+  launch_plane_partial_sums(x, batch, h, w, partial, (hipStream_t)stream);
   int rc = dvc::check_launch("plane_partial_sum_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, x->channels,
@@ -398,8 +432,7 @@ extern "C" int dvc_se_gate_static(const DvcSrc* x, int32_t batch, int32_t h, int
   float* partial = nullptr;
   if (int rc = static_scratch(&partial)) return rc;
   // every (n, c, slice) partial sum this call reads is written by its first kernel: nothing to clear
-  hipLaunchKernelGGL(plane_partial_sum_kernel, dim3(SE_SLICES, x->channels, batch), dim3(256), 0, (hipStream_t)stream,
-                     mk(x), h, w, partial);
+  launch_plane_partial_sums(x, batch, h, w, partial, (hipStream_t)stream);
   int rc = dvc::check_launch("plane_partial_sum_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, x->channels,

@@ -10,7 +10,9 @@ whose pre-rounding value in the oracle lies within 2e-3 of x.5.  round() sits in
 two fp32 implementations with different summation orders may disagree on such a latent, and the flipped
 symbol then moves the means / the decoded flow around it (measured: frame 1 no difference at all, frame 2
 one motion tie and 139 latents in its wake, dbpp -2.5e-6).
-The fp16 hi+lo split arithmetic (never the benchmark value) is run beside it and held to 5x those bars.
+The 16-bit-operand modes (never the benchmark value) are run beside it: the hi+lo split modes (fp16x2, and
+bf16x2 on the bf16 matrix instruction) are held to the same PSNR / bpp bars, the single-part bf16 mode misses
+them and is pinned at 20x.
 The oracle needs ~10 s per frame on 16 cores."""
 import math
 
@@ -26,6 +28,11 @@ BPP_TOL = 1e-4
 N_LATENTS = 160 * 68 * 120
 FLIP_FRACTION = 1e-4
 N_FRAMES = 3
+# mode -> (multiple of the PSNR / bpp bars, multiple of the flip bar, flips must start at a rounding tie).
+# Measured (3 frames): fp32 |dPSNR| <= 3e-6 dB, |dbpp| <= 2e-6, 31 latents; fp16x2 2e-6 / 1e-6 / 35; bf16x2 (bf16 hi+lo
+# parts on the bf16 MFMA) 4e-5 / 7e-7 / 382 -- all inside the bar; bf16 (one bf16 part) 7e-3 dB / 3e-5 bpp / 15 700
+# latents: outside it, held here to 20x as a regression bound only.
+MODES = {"fp32": (1.0, 1.0, True), "fp16x2": (1.0, 1.0, True), "bf16x2": (1.0, 5.0, False), "bf16": (20.0, 200.0, False)}
 
 
 def _near_tie(pre, tol=2e-3):
@@ -56,7 +63,7 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
                 p_o, b_o = psnr(frames[i], x_o), bpp(lik_o, n_pix)
                 rate[i] = (b_o, p_o)
                 dpb_g = {k: (None if v is None else v.cuda()) for k, v in dpb.items()}
-                for mode in ("fp32", "fp16x2"):
+                for mode in MODES:
                     gpu_net.set_precision(mode)
                     x_g, lik_g, ctx_g = gpu_net.forward_inter(frames[i].cuda(), dpb_g)
                     lik_g = {a: {b: t.cpu() for b, t in v.items()} for a, v in lik_g.items()}
@@ -78,10 +85,11 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
     for i, (b_o, _) in rate.items():
         assert 0.02 <= b_o <= 1.0, f"frame {i}: {b_o} bpp is not a realistic operating point for the parity bar"
     for i, mode, d_psnr, d_bpp, flips, has_origin in report:
-        k = 1.0 if mode == "fp32" else 5.0
+        k, _, tie_origin = MODES[mode]
         assert abs(d_psnr) <= k * PSNR_TOL, (i, mode, d_psnr)
         assert abs(d_bpp) <= k * BPP_TOL, (i, mode, d_bpp)
-        assert has_origin, f"frame {i} {mode}: {flips} latents differ and none of them starts at a rounding tie"
-    for mode, k in (("fp32", 1.0), ("fp16x2", 5.0)):
+        if tie_origin:
+            assert has_origin, f"frame {i} {mode}: {flips} latents differ and none of them starts at a rounding tie"
+    for mode, (_, kf, _) in MODES.items():
         total = sum(r[4] for r in report if r[1] == mode)
-        assert total <= k * FLIP_FRACTION * N_LATENTS * N_FRAMES, (mode, total)
+        assert total <= kf * FLIP_FRACTION * N_LATENTS * N_FRAMES, (mode, total)
