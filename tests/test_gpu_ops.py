@@ -156,6 +156,32 @@ def test_flow_warp_large_and_views():
     close(z, feat, rel=1e-3)
 
 
+@pytest.mark.parametrize("h,w,batch", [(68, 120, 1), (100, 132, 16), (272, 480, 2), (544, 960, 1), (1088, 1920, 1)])
+def test_flow_warp_window_kernel_equals_direct_gather(h, w, batch):
+    """Tensors with >= 16 channels and >= 256 tiles of 64 x 16 pixels (all cases here but the first) go through the
+    LDS-window kernel, thinner ones through the direct gather:
+    the same planes warped 8 channels at a time must come out bit-identical, for motion that fits the window,
+    motion that does not (tiles fall back inside the kernel), and positions clipped at every border."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(h + w)
+    feat = dev(torch.randn(batch, 40, h, w, generator=g))
+    smooth = F.interpolate(torch.randn(batch, 2, max(h // 16, 2), max(w // 16, 2), generator=g) * 2.5, size=(h, w),
+                           mode="bilinear", align_corners=False)
+    flows = {
+        "smooth": smooth,
+        "noise": torch.randn(batch, 2, h, w, generator=g) * 1.5,
+        "large": torch.randn(batch, 2, h, w, generator=g) * 40,
+        "shift": smooth * 0.1 + torch.tensor([37.25, -21.5]).view(1, 2, 1, 1),
+        "clip": torch.cat([torch.full((batch, 1, h, w), float(w)), torch.full((batch, 1, h, w), -float(h))], 1),
+    }
+    for name, flow in flows.items():
+        flow = dev(flow.contiguous())
+        got = ops.flow_warp(feat, flow)
+        want = torch.cat([ops.flow_warp(feat[:, c:c + 8].contiguous(), flow) for c in range(0, 40, 8)], 1)
+        assert torch.equal(got, want), (name, float((got - want).abs().max()))
+        close(got, O.flow_warp(feat.cpu(), flow.cpu()), rel=5e-5)
+
+
 def test_pools_and_scaled_resampling():
     from deepvideocodec_amd import ops
     g = torch.Generator().manual_seed(3)
