@@ -123,7 +123,9 @@ class ConvProbe:
         from deepvideocodec_amd import ops
         self.ops = ops
         self.orig = ops.conv2d
+        self.orig_warp, self.orig_se = ops.flow_warp, ops.se_gate
         self.records = []
+        self.hbm_records = []   # (kernel, algorithmic bytes, start event, end event) of the HBM-bound kernels
 
     def __enter__(self):
         def probed(srcs, weight, bias, stride=1, **kw):
@@ -144,11 +146,40 @@ class ConvProbe:
             e1.record()
             self.records.append(((k, stride, mt, nt), flops, e0, e1, nbytes))
             return out
+        def bracket(name, nbytes, fn, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.hbm_records.append((name, nbytes, e0, e1))
+            return out
+
+        def probed_warp(src, flow, out=None):
+            n, c, h, w = src.shape   # every source and output element once, plus the flow: (2 C + 2) * 4 bytes per pixel
+            return bracket("flow_warp", 4.0 * n * (2 * c + 2) * h * w, self.orig_warp, src, flow, out=out)
+
+        def probed_se(x, fc1, fc2):
+            return bracket("se_gate (plane sums + gate)", 4.0 * x.numel(), self.orig_se, x, fc1, fc2)
         self.ops.conv2d = probed
+        self.ops.flow_warp, self.ops.se_gate = probed_warp, probed_se
         return self
 
     def __exit__(self, *a):
         self.ops.conv2d = self.orig
+        self.ops.flow_warp, self.ops.se_gate = self.orig_warp, self.orig_se
+
+    def hbm_summary(self):
+        """Per HBM-bound kernel: launches, algorithmic bytes and achieved GB/s over the probed frames."""
+        torch.cuda.synchronize()
+        per = {}
+        for name, nbytes, e0, e1 in self.hbm_records:
+            d = per.setdefault(name, [0.0, 0.0, 0])
+            d[0] += nbytes
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        return {k: {"launches": v[2], "algorithmic_bytes": v[0], "ms": v[1] * 1e3, "achieved": v[0] / v[1] / 1e9,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": v[0] / v[1] / 1e9 / PEAK_HBM_GBS}
+                for k, v in per.items() if v[1] > 0}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -437,6 +468,7 @@ def main():
                 "frac": fl / tm / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(kname),
                 "launches": cnt, "avg_launch_ms": tm / cnt * 1e3, "gflop_per_launch": fl / cnt / 1e9,
                 "algorithmic_bytes_per_launch": nb / cnt,
+                "hbm_bound_kernels": probe.hbm_summary(),
                 "all_conv_variants": {"achieved": all_flops / all_time / 1e12,
                                       "frac": all_flops / all_time / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                       "conv_ms_per_frame": all_time / 2 * 1e3,

@@ -94,6 +94,17 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(Src src, Src flow, Dst o
 // Needs w % 4 == 0 and 16-byte aligned planes; blockIdx.y = sample.
 constexpr int WARP_WIN_FLOATS = 2560;   // per LDS buffer (10 KiB)
 
+// Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2: renumber the tiles so
+// that each XCD works through one contiguous row-major range (neighbouring tiles' windows overlap).
+// bx of nt workgroups in a grid row whose first workgroup has launch phase s (= launch index mod 8).
+__device__ __forceinline__ int xcd_contiguous_tile(int bx, int nt, int s) {
+  const int u = bx + s, k = u & 7;
+  const int m1 = s + nt;
+  const int before = (m1 >> 3) * k + min(m1 & 7, k) - min(s, k);   // slots of this row that land on XCDs < k
+  const int first_u = s + ((k - s) & 7);
+  return before + ((u - first_u) >> 3);
+}
+
 template <int RPL>
 __global__ __launch_bounds__(256) void flow_warp_lds_kernel(Src src, Src flow, Dst out, int h, int w, int tiles_x) {
   constexpr int TH = 4 * RPL;
@@ -101,7 +112,8 @@ __global__ __launch_bounds__(256) void flow_warp_lds_kernel(Src src, Src flow, D
   __shared__ __attribute__((aligned(16))) float win[2][WARP_WIN_FLOATS];
   __shared__ int red[4][4];
   const int n = blockIdx.y;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x, (int)((blockIdx.y * gridDim.x) & 7));
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x = tx * 64 + lane, yb = ty * TH + wave * RPL;
   const float* const sp = src.p + n * src.bs;
