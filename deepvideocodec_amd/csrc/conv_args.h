@@ -32,6 +32,13 @@ struct ConvArgs {
 constexpr int conv_chunk_of(int ks, int s) { return ks == 7 ? 2 : ks == 1 ? 16 : (s == 2 ? 4 : 8); }
 constexpr int conv_slab_floats(int ks, int s, int cb) { return (conv_chunk_of(ks, s) * ks * ks * cb + 255) / 256 * 256; }
 
+// Row-pair image of a 7x7 stride-1 layer with exactly 16 output channels (appended to the ordinary image by
+// dvc_conv2d_pack_weight): a 32-row block whose rows 0..15 are the filters and rows 16..31 the same filters moved
+// one tap row down, over 8 x 7 taps -- one pass of the 32-row matrix instruction then yields two output rows.
+constexpr int CONV_ROWPAIR_COUT = 16, CONV_ROWPAIR_TAPS = 8 * 7;
+constexpr bool conv_has_rowpair_image(int cout, int ks, int s) { return ks == 7 && s == 1 && cout == CONV_ROWPAIR_COUT; }
+constexpr int conv_rowpair_slab_floats() { return (conv_chunk_of(7, 1) * CONV_ROWPAIR_TAPS * 32 + 255) / 256 * 256; }
+
 // conv_mfma_*.hip: the MFMA kernel variants, split over translation units by shape and precision
 // (ksize / stride select inside a unit; the caller has validated them)
 int conv_mfma_run_f32_k3s1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);

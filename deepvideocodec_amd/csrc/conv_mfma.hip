@@ -65,6 +65,24 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
   }
 }
 
+// Row-pair image of a 7x7 layer with 16 output channels: [chunk][row = (ci - c0) * 56 + ky' * 7 + kx][32 columns],
+// column dy * 16 + co = w[co][ci][ky' - dy][kx] where that tap row exists, else 0.
+__global__ __launch_bounds__(256) void pack_weight_rowpair_kernel(const float* w, float* packed, int cin, int ck, int slab,
+                                                                  int nchunks, long long total) {
+  constexpr int taps = dvc::CONV_ROWPAIR_TAPS;
+  static_assert(dvc::CONV_ROWPAIR_COUT == 16, "column = dy * 16 + co");
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i % slab), chunk = (int)(i / slab);
+    const int row = e / 32, col = e - row * 32;
+    const int ci = chunk * ck + row / taps, tap = row % taps;
+    const int kyp = tap / 7, kx = tap - kyp * 7;
+    const int dy = col >> 4, co = col & 15, ky = kyp - dy;
+    float v = 0.f;
+    if (row < ck * taps && ci < cin && ky >= 0 && ky < 7) v = w[((long long)co * cin + ci) * 49 + ky * 7 + kx];
+    packed[i] = v;
+  }
+}
+
 int check_geometry(int cout, int cin, int ks, int stride, const char* who) {
   DVC_REQUIRE(ks == 1 || ks == 3 || ks == 7, "%s: ksize=%d unsupported", who, ks);
   DVC_REQUIRE(stride == 1 || stride == 2, "%s: stride=%d unsupported", who, stride);
@@ -79,7 +97,10 @@ int check_geometry(int cout, int cin, int ks, int stride, const char* who) {
 extern "C" int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride) {
   if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_packed_weight_floats")) return DVC_EINVAL;
   const int cb = cout_block_of(cout), ck = chunk_of(ksize, stride);
-  return (int64_t)((cout + cb - 1) / cb) * ((cin + ck - 1) / ck) * slab_floats(ksize, stride, cb);
+  const int64_t nchunks = (cin + ck - 1) / ck;
+  int64_t total = (int64_t)((cout + cb - 1) / cb) * nchunks * slab_floats(ksize, stride, cb);
+  if (dvc::conv_has_rowpair_image(cout, ksize, stride)) total += nchunks * dvc::conv_rowpair_slab_floats();
+  return total;
 }
 
 extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
@@ -92,7 +113,15 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
   const long long total = (long long)((cout + cb - 1) / cb) * nchunks * slab;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
                      packed, cout, cin, ksize, ck, cb, slab, nchunks, total);
-  return dvc::check_launch("pack_weight_kernel");
+  if (int rc = dvc::check_launch("pack_weight_kernel")) return rc;
+  if (dvc::conv_has_rowpair_image(cout, ksize, stride)) {   // second image behind the first (see launch_rowpair)
+    const int rslab = dvc::conv_rowpair_slab_floats();
+    const long long rtotal = (long long)nchunks * rslab;
+    hipLaunchKernelGGL(pack_weight_rowpair_kernel, dim3(dvc::stream_grid(rtotal, 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, packed + total, cin, ck, rslab, nchunks, rtotal);
+    return dvc::check_launch("pack_weight_rowpair_kernel");
+  }
+  return DVC_OK;
 }
 
 extern "C" int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,

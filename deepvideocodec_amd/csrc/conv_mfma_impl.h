@@ -88,9 +88,14 @@ constexpr int min_waves_per_simd() { return 2; }
 // 3 = the same split with fp16 parts on v_mfma_f32_32x32x16_f16: hi = fp16(v), lo = fp16(v - hi) carry 22
 // significant bits (absolute floor 2^-25 from the fp16 subnormals, which the MFMA keeps), so a product is
 // within ~2^-21 of the fp32 one; operands saturate at +-65504 (hi) + 65504 (lo).
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
+// DY = 2 (7x7 stride 1, 16 output channels, MT = 1): the row-pair form.  The 32 MFMA rows are the 16 filters and
+// the same 16 filters moved one tap row down, so one accumulator tile holds two output rows of 32 pixels; the tap
+// grid is 8 x 7 and a wave's tiles are two input rows apart.  8 x 7 MFMA steps per two output rows instead of
+// 2 x 7 x 7, and the sums are those of the ordinary form (the extra terms are exact zeros).
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
 struct Geo {
   static_assert(!HALF || MT == 1, "half blocks are 32 channels");
+  static_assert(DY == 1 || (DY == 2 && KS == 7 && S == 1 && MT == 1 && !HALF && BF == 0), "row pairs: 7x7 stride 1 fp32");
   static_assert(!BF || KS != 7, "the reduced-operand modes cover the 1x1 and 3x3 layers");
   static constexpr int PARTS = BF >= 2 ? 2 : 1;
   static constexpr bool F16 = BF == 3;
@@ -98,13 +103,16 @@ struct Geo {
   static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
-  static constexpr int IH = (TH - 1) * SL + KS;
+  static constexpr int KSY = KS + DY - 1;        // tap rows
+  static constexpr int SLY = DY > 1 ? DY : SL;   // input rows between two tile rows
+  static constexpr int IH = (TH - 1) * SLY + KSY;
   static constexpr int IW = (TW - 1) * SL + KS;
   static constexpr int CHS = IH * IW;            // floats per staged channel
-  static constexpr int TAPS = KS * KS;
+  static constexpr int TAPS = KSY * KS;
   static constexpr int KCH = CK * TAPS;          // k values per chunk
   static constexpr int CBP = HALF ? 64 : CB;     // output channels per packed weight row
-  static constexpr int SLAB = BF ? PARTS * slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
+  static constexpr int SLAB = DY > 1 ? dvc::conv_rowpair_slab_floats()
+                              : BF ? PARTS * slab_floats_bf16(KS, CBP) : slab_floats(KS, S, CBP);   // in 4-byte units
   // fp32: [channel][element]; bf16: [octet][element][8 channels] = 8 * CHS 4-byte units
   static constexpr int IN_BUF = ((BF ? 8 * PARTS : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
@@ -149,11 +157,11 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #define DVC_CSTAMP(cond, slot)
 #endif
 
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
 __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
-  using G = Geo<KS, S, MT, NT, HALF, BF>;
+  using G = Geo<KS, S, MT, NT, HALF, BF, DY>;
   constexpr int CBP = G::CBP;
-  constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW;
+  constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW, SLY = G::SLY;
   constexpr int CHS = G::CHS, TAPS = G::TAPS, SLAB = G::SLAB, IN_BUF = G::IN_BUF, IN_PT = G::IN_PT, GS = G::GS;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -186,12 +194,16 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const int wblock = HALF ? (int)(blockIdx.y >> 1) : (int)blockIdx.y;   // packed weight block
   const int cb0 = HALF ? wblock * 64 + (int)(blockIdx.y & 1) * 32 : wblock * CB;
   if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
-  if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
+  if constexpr (DY > 1) {   // rows 16..31 are the 16 channels again
+    if (tid < CB) bias_s[tid] = a.bias != nullptr ? a.bias[tid & 15] : 0.f;
+  } else {
+    if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
+  }
   const int n = blockIdx.z;
   const int nchunks = (a.cin + CK - 1) / CK;
 
   // ---- per-thread staging descriptors (identical for every channel and chunk)
-  const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
+  const int gy0 = (KS == 1) ? oy0 * S : oy0 * (DY > 1 ? DY : S) - PAD;   // (row pairs: oy0 counts pairs)
   const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
   // byte offset of each staged element inside its channel plane; padding elements get an offset
   // past every plane, for which the buffer load returns 0 (hardware range check) -- zero padding
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const int b_lane = half * CHS + (wave * NT * SL) * IW + l32 * SL;
+  const int b_lane = half * CHS + (wave * NT * SLY) * IW + l32 * SL;
   const int a_lane = (half * TAPS) * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
   // bf16 mode, in 16-byte units: A [tap][octet][co], B [octet][element]
   const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
         });
         static_for<NT>([&](auto nc) __attribute__((always_inline)) {
           constexpr int nt = decltype(nc)::value;
-          bv[slot][nt] = lds_read_imm<4 * (2 * cp * CHS + (nt * SL + ky) * IW + kx)>(b_addr);
+          bv[slot][nt] = lds_read_imm<4 * (2 * cp * CHS + (nt * SLY + ky) * IW + kx)>(b_addr);
         });
       };
       static_assert(4 * (CK * TAPS * CBP + 32) < 65536 && 4 * (CK * CHS) < 65536, "operand offsets exceed the DS offset field");
@@ -588,6 +600,45 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
   const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
 
+  if constexpr (DY > 1) {
+    // Row pairs (launched only for sizes the tile divides, 16-byte aligned rows, no residual / shuffle): rows
+    // 0..15 of an accumulator tile are output row 2p, rows 16..31 output row 2p + 1 of channels 0..15.  The same
+    // trip through the wave's LDS tile as below; piece q of a lane = channel 8 (q & 1) + sub of row 2p + (q >> 1).
+    constexpr int RS = 36;
+    float* const tl = lds + wave * (32 * RS);
+    const int sub = lane >> 3, px4 = 4 * (lane & 7);
+    const unsigned o_lane = (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
+    const int lds_lane = sub * RS + px4;
+    const float out_slope = a.out_slope;
+    float4 cur[4];
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[4 * half + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) {
+      if (i < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = f32x2{acc[0][i][r], acc[0][i][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
+          const f32x2 sv = v * out_slope;
+          tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
+          tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
+        }
+      }
+      if (i > 0) {
+        const long long row0 = 2LL * (oy0 + wave * NT + (i - 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(out_n + (long long)(8 * (q & 1)) * a.ocs + (row0 + (q >> 1)) * a.wo + ox0 + o_lane) = cur[q];
+      }
+      if (i < NT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
+      }
+    }
+    DVC_STAMP(3);
+    return;
+  }
   if (a.vec4) {
     // Fast path (everything 16-byte aligned).  Store instructions, not bytes, are what the epilogue
     // pays for, so each 32 channel x 32 pixel accumulator tile is turned through a wave-private LDS
@@ -883,9 +934,9 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   }
 }
 
-template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0>
+template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
 int launch(const ConvArgs& a, int batch, hipStream_t st) {
-  using G = Geo<KS, S, MT, NT, HALF, BF>;
+  using G = Geo<KS, S, MT, NT, HALF, BF, DY>;
   // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
   // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
   static std::atomic<unsigned long long> attr_done{0};
@@ -893,7 +944,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
   const unsigned long long device_bit = 1ull << device;
   if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(conv %d,%d,%d,%d): %s", KS, S, MT, NT, hipGetErrorString(e));
@@ -902,10 +953,10 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
     attr_done.fetch_or(device_bit, std::memory_order_release);
   }
   ConvArgs b = a;
-  const int tiles_y = (a.ho + G::TH - 1) / G::TH;
+  const int tiles_y = (a.ho + G::TH * DY - 1) / (G::TH * DY);
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
   dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF>), grid, dim3(256), G::LDS_BYTES, st, b);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>), grid, dim3(256), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
 }
 
@@ -921,6 +972,29 @@ inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
     if (blocks >= 480) return nt;   // (within a few percent of two workgroups per CU counts)
   }
   return 1;
+}
+
+// 7x7 stride 1 with exactly 16 output channels (the fourth layer of every SpyNet level: half the MFMA rows would
+// idle): the row-pair form, when the launch is one it covers -- whole tiles, 16-byte rows, plain epilogue -- with
+// the tallest tile that divides the height and still yields two workgroups per CU.  `rowpair_image`: where the
+// packed row-pair image starts (behind the ordinary one).  Returns -1 when the ordinary form has to run.
+inline int launch_rowpair(const ConvArgs& a, int batch, hipStream_t st) {
+  if (!dvc::conv_has_rowpair_image(a.cout, 7, 1) || !a.vec4 || a.res != nullptr || a.ps || a.wo % 32 != 0 ||
+      a.out_slope < 0.f || a.out_slope > 1.f)
+    return -1;
+  const int nchunks = (a.cin + chunk_of(7, 1) - 1) / chunk_of(7, 1);
+  ConvArgs b = a;
+  b.wpacked = a.wpacked + (long long)nchunks * slab_floats(7, 1, 32);
+  const long long tx = a.wo / 32;
+  for (int nt = 4; nt >= 1; nt >>= 1) {
+    if (a.ho % (8 * nt) != 0) continue;
+    const long long blocks = (long long)(a.ho / (8 * nt)) * tx * batch;
+    if (blocks < 480 && nt > 1) continue;
+    if (nt == 4) return launch<7, 1, 1, 4, false, 0, 2>(b, batch, st);
+    if (nt == 2) return launch<7, 1, 1, 2, false, 0, 2>(b, batch, st);
+    return launch<7, 1, 1, 1, false, 0, 2>(b, batch, st);
+  }
+  return -1;
 }
 
 template <int KS, int S, int BF = 0>

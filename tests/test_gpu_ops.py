@@ -510,3 +510,34 @@ def test_conv2d_few_output_channels(k, cin, cout, H, W, batch, in_slope, out_slo
                out=out_big[:, 2:2 + cout])
     close(out_big[:, 2:2 + cout], want)
     assert float(out_big[:, :2].abs().max()) == 0.0 and float(out_big[:, 2 + cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,H,W,batch,in_slope,out_slope", [
+    (32, 64, 64, 2, None, 0.0),      # 4-row tiles
+    (32, 560, 960, 1, None, 0.0),    # 8-row tiles (35 x 30 workgroups)
+    (32, 544, 960, 1, 0.1, 0.0),     # 16-row tiles (17 x 30 workgroups), activation on the input
+    (2, 64, 96, 1, None, None),      # a single ragged chunk (the data gradient of a 16 -> 2 layer)
+    (32, 72, 64, 1, None, 0.0),      # height 72 = 9 x 8: only the 4-row tile divides it
+    (32, 68, 64, 1, None, 0.0),      # height the row-pair tiles do not divide: ordinary form
+])
+def test_conv2d_7x7_sixteen_channels_row_pairs(cin, H, W, batch, in_slope, out_slope):
+    """7x7 layers with exactly 16 output channels run in the row-pair form (two output rows per accumulator
+    tile) where its tiles divide the plane.  Same sums as the ordinary form: the first 16 channels of the same
+    layer widened to 17 output channels (ordinary form) must be bit-identical, and both match the torch conv.
+    The destination is a channel slice of a larger buffer."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(cin * 1000 + H)
+    x = torch.randn(batch, cin, H, W, generator=g)
+    w = torch.randn(17, cin, 7, 7, generator=g) / math.sqrt(cin * 49)
+    b = torch.randn(17, generator=g)
+    xin = F.leaky_relu(x, in_slope) if in_slope is not None else x
+    want = F.conv2d(xin, w[:16], b[:16], padding=3)
+    if out_slope is not None:
+        want = F.leaky_relu(want, out_slope)
+    out_big = torch.zeros(batch, 21, H, W, device="cuda:0")
+    ops.conv2d(dev(x), dev(w[:16].contiguous()), dev(b[:16].contiguous()), in_slope=in_slope, out_slope=out_slope,
+               out=out_big[:, 2:18])
+    wide = ops.conv2d(dev(x), dev(w), dev(b), in_slope=in_slope, out_slope=out_slope)
+    close(out_big[:, 2:18], want)
+    assert torch.equal(out_big[:, 2:18], wide[:, :16]), float((out_big[:, 2:18] - wide[:, :16]).abs().max())
+    assert float(out_big[:, :2].abs().max()) == 0.0 and float(out_big[:, 18:].abs().max()) == 0.0
