@@ -104,7 +104,11 @@ int dvc_conv2d(const DvcConv2d* p, void* stream);
  * channels and per K-chunk of input channels, one contiguous zero-padded slab
  * [(ci - c0) * k*k + tap][co - cb0], so a slab is fetched global -> LDS in 1 KiB pieces.
  * Re-pack whenever the nn.Conv2d weight (OIHW) changes.  The packed size depends on
- * (Cout, Cin, k, stride); dvc_conv2d_packed_weight_floats returns it (negative on error). */
+ * (Cout, Cin, k, stride); dvc_conv2d_packed_weight_floats returns it (negative on error).
+ * For 7x7 stride-1 layers with exactly 16 output channels a second image follows the first inside the
+ * same buffer (the filters paired with a copy moved one tap row down, 8 x 7 taps x 32 columns per
+ * input channel): dvc_conv2d uses it to compute two output rows per matrix-instruction pass where
+ * the launch allows.  The returned size covers both. */
 int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
