@@ -47,6 +47,7 @@ class DvcConv2d(C.Structure):
         ("residual2", C.c_void_p),
         ("res2_batch_stride", C.c_int64), ("res2_chan_stride", C.c_int64),
         ("precision", C.c_int32), ("_pad", C.c_int32),
+        ("plane_sums", C.c_void_p),
     ]
 
 
@@ -58,6 +59,7 @@ _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 # name -> (restype, argtypes); must list every symbol include/dvc_hip.h declares.
 SIGNATURES = {
     "dvc_conv2d": (C.c_int, [C.POINTER(DvcConv2d), _P]),
+    "dvc_conv2d_plane_sum_slots": (_i32, [C.POINTER(DvcConv2d)]),
     "dvc_conv2d_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "dvc_conv2d_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
     "dvc_conv2d_reduced_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "dvc_spynet_level_input": (C.c_int, [_SRC, _SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_se_scratch_floats": (_i64, [_i32, _i32]),
     "dvc_se_gate": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _i32, _P, _P, _P]),
+    "dvc_se_gate_from_sums": (C.c_int, [_P, _i32, _i32, _i32, _i32, _i32, _P, _P, _i32, _P, _P, _P]),
     "dvc_se_gate_static": (C.c_int, [_SRC, _i32, _i32, _i32, _P, _P, _i32, _P, _P]),
     "dvc_copy": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_clamp": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _f32, _f32, _P]),

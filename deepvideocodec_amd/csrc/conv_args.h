@@ -26,6 +26,8 @@ struct ConvArgs {
   int tiles_x;
   int vec4;               // output / residual rows allow 16-byte accesses
   int soff_ok;            // every source spans < 2 GiB per sample: a channel can be a 32-bit scalar offset
+  float* plane_sums;      // optional [batch][cout][sum_slots]: per-workgroup sums of the stored output planes
+  int sum_slots;          // workgroups per (sample, channel block) of this launch
 };
 
 // fp32 packed weights (dvc_conv2d_pack_weight): input channels per K-chunk and floats per slab

@@ -155,7 +155,9 @@ extern "C" int dvc_conv2d_reduced_pack_weight(const float* weight, int32_t cout,
   return dvc::check_launch("pack_weight_half_kernel");
 }
 
-extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
+namespace {
+// Validates the parameters and fills the launch arguments (everything but the tile choice).
+int build_conv_args(const DvcConv2d* p, ConvArgs& a) {
   DVC_REQUIRE(p != nullptr, "dvc_conv2d: null params");
   DVC_REQUIRE(p->n_src >= 1 && p->n_src <= DVC_MAX_SRC, "dvc_conv2d: n_src=%d not in 1..%d", p->n_src, DVC_MAX_SRC);
   DVC_REQUIRE(p->batch >= 1 && p->in_h >= 1 && p->in_w >= 1, "dvc_conv2d: bad dims");
@@ -164,7 +166,7 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(p->weight_packed != nullptr && p->out.ptr != nullptr, "dvc_conv2d: null weight/out");
   DVC_REQUIRE(reinterpret_cast<uintptr_t>(p->weight_packed) % 16 == 0, "dvc_conv2d: packed weight must be 16-byte aligned");
   DVC_REQUIRE(!p->pixel_shuffle || p->out_channels % 4 == 0, "dvc_conv2d: pixel_shuffle needs Cout %% 4 == 0");
-  ConvArgs a{};
+  a = ConvArgs{};
   int cin = 0;
   for (int s = 0; s < p->n_src; ++s) {
     DVC_REQUIRE(p->src[s].ptr != nullptr && p->src[s].channels >= 1, "dvc_conv2d: bad source %d", s);
@@ -228,6 +230,22 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   a.out_slope = p->out_act ? p->out_slope : 1.0f;
   a.in_act = p->in_act ? 1 : 0;
   a.out_act = p->out_act ? 1 : 0;
+  a.plane_sums = p->plane_sums;
+  return DVC_OK;
+}
+}  // namespace
+
+extern "C" int32_t dvc_conv2d_plane_sum_slots(const DvcConv2d* p) {
+  ConvArgs a;
+  if (int rc = build_conv_args(p, a)) return rc;
+  return conv_plane_sum_slots(a, p->ksize, p->stride, p->precision, p->batch);
+}
+
+extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
+  ConvArgs a;
+  if (int rc = build_conv_args(p, a)) return rc;
+  DVC_REQUIRE(a.plane_sums == nullptr || conv_plane_sum_slots(a, p->ksize, p->stride, p->precision, p->batch) > 0,
+              "dvc_conv2d: plane_sums is not available for this launch (dvc_conv2d_plane_sum_slots() == 0)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p->precision != DVC_PRECISION_FP32) {
     DVC_REQUIRE(p->ksize != 7 && p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,

@@ -118,7 +118,8 @@ struct Geo {
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
   static constexpr int STAGE_BYTES = NBUF * (IN_BUF + SLAB) * 4;
-  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4;   // four wave-private 32 x 36 transposition tiles
+  // four wave-private 32 x 36 transposition tiles + the four waves' per-channel sums (plane-sum output)
+  static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + 4 * 64 * 4;
   static constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   static constexpr int LDS_BYTES = MAIN_BYTES + 64 * 4;   // + this workgroup's (up to 64) bias values
 };
@@ -735,9 +736,21 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     // residuals added and is stored (LDS executes a wave's accesses in order, so the single tile buffer
     // needs no waits between tiles).  Addresses are a wave-uniform base per (tile, channel octet) plus one
     // 32-bit per-lane offset computed once; the bias comes from LDS.
-    auto run_full = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c) {
+    auto run_full = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c, auto sums_c) {
       constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
       constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
+      // SUMS: also emit, per output channel, the sum of the values this workgroup stores (the first stage of a
+      // deterministic two-stage plane sum: the squeeze-excite gate needs the plane means of this very tensor, and
+      // a separate pass would read all of it back from HBM)
+      constexpr bool SUMS = decltype(sums_c)::value;
+      static_assert(!SUMS || (!RES && !PS), "plane sums: plain stores without residual");
+      float psum[MT][4];
+      if constexpr (SUMS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) psum[mt][q] = 0.f;
+      }
       // plain: 8 lanes x 16 B per channel row; piece q of a lane = channel 8q + sub, pixels px4 .. px4+3.
       // shuffle: conv channel co -> stored channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); 16 lanes x 16 B
       // per stored row; piece q = stored channel 2q + (row>>1), row parity row&1, conv pixels px2, px2+1 of the
@@ -791,6 +804,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
             }
           }
           *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix + o_lane) = v;
+          if constexpr (SUMS) psum[mt][q] += (v.x + v.y) + (v.z + v.w);
         }
       };
 #pragma unroll
@@ -832,6 +846,25 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
           }
         }
       }
+      if constexpr (SUMS) {
+        // a lane's psum[mt][q] covers 4 pixels x NT rows of channel 32 mt + 8 q + sub; the 8 lanes of a channel
+        // are adjacent: fold them, then the four waves through LDS, always in the same order
+        float* const red = lds + 4 * (32 * RS);   // [wave][CB], behind the transposition tiles
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float s = psum[mt][q];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if ((lane & 7) == 0) red[wave * CB + mt * 32 + 8 * q + sub] = s;
+          }
+        __syncthreads();
+        if (tid < CB)
+          a.plane_sums[((long long)n * a.cout + cb0 + tid) * a.sum_slots + tile] =
+              (red[tid] + red[CB + tid]) + (red[2 * CB + tid] + red[3 * CB + tid]);
+      }
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -840,15 +873,25 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
                       a.out_slope >= 0.f && a.out_slope <= 1.f;
     auto by_shuffle = [&](auto res_c, auto scale_c, auto res2_c) {
       if (full) {
-        if (a.ps) run_full(res_c, scale_c, res2_c, T{});
-        else run_full(res_c, scale_c, res2_c, F{});
+        if (a.ps) run_full(res_c, scale_c, res2_c, T{}, F{});
+        else run_full(res_c, scale_c, res2_c, F{}, F{});
       } else if (a.ps) {
         run(res_c, scale_c, res2_c, T{});
       } else {
         run(res_c, scale_c, res2_c, F{});
       }
     };
-    if (!has_res) by_shuffle(F{}, F{}, F{});
+    if (!has_res) {
+      // (plane sums are requested only for launches made of whole tiles -- conv_plane_sum_slots on the host)
+      if constexpr (KS == 3 && S == 1 && BF == 0 && !HALF && DY == 1) {
+        if (a.plane_sums != nullptr && full && !a.ps) {
+          run_full(F{}, F{}, F{}, F{}, T{});
+          DVC_STAMP(3);
+          return;
+        }
+      }
+      by_shuffle(F{}, F{}, F{});
+    }
     else if (has_scale) { if (has_res2) by_shuffle(T{}, T{}, T{}); else by_shuffle(T{}, T{}, F{}); }
     else { if (has_res2) by_shuffle(T{}, F{}, T{}); else by_shuffle(T{}, F{}, F{}); }
     DVC_STAMP(3);
@@ -955,6 +998,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   ConvArgs b = a;
   const int tiles_y = (a.ho + G::TH * DY - 1) / (G::TH * DY);
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
+  b.sum_slots = b.tiles_x * tiles_y;
   dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>), grid, dim3(256), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
@@ -995,6 +1039,21 @@ inline int launch_rowpair(const ConvArgs& a, int batch, hipStream_t st) {
     return launch<7, 1, 1, 1, false, 0, 2>(b, batch, st);
   }
   return -1;
+}
+
+// Partial sums per output plane that a 3x3 stride-1 fp32 launch can emit with its stores (ConvArgs::plane_sums):
+// one per workgroup tile, when the launch is made of whole tiles of the variant dispatch_tile<3, 1, 0> picks, has
+// 16-byte rows, no residual and no PixelShuffle.  0: not available for this launch.
+inline int conv_plane_sum_slots(const ConvArgs& a, int ksize, int stride, int precision, int batch) {
+  if (precision != 0 || ksize != 3 || stride != 1 || a.ps || !a.vec4 || a.res != nullptr || a.out_slope < 0.f ||
+      a.out_slope > 1.f || dvc::thin_conv_applies(a, ksize, stride, batch))
+    return 0;
+  const int mt = a.cout > 32 ? 2 : 1;
+  const int nt = pick_nt(a, batch, mt, 4);
+  if (mt == 2 && nt == 1) return 0;   // (small launches: half blocks / 4-row tiles, not covered)
+  if (a.cout % (32 * mt) != 0 || a.ho % (4 * nt) != 0 || a.wo % 32 != 0) return 0;
+  const long long slots = (long long)(a.ho / (4 * nt)) * (a.wo / 32);
+  return slots <= 65536 ? (int)slots : 0;
 }
 
 template <int KS, int S, int BF = 0>

@@ -404,6 +404,17 @@ void launch_plane_partial_sums(const DvcSrc* x, int batch, int h, int w, float* 
   else hipLaunchKernelGGL(plane_partial_sum_kernel<false>, grid, dim3(256), 0, st, mk(x), h, w, partial);
 }
 
+// Second stage for plane sums that came out of a convolution's epilogue (one value per workgroup tile, `slots` per
+// plane): one wave per plane folds them into the SE_SLICES partial sums se_fc_kernel reads -- lane l takes the slots
+// congruent to l, so the order is fixed.
+__global__ __launch_bounds__(64) void fold_plane_sums_kernel(const float* sums, int slots, float* partial) {
+  const long long plane = blockIdx.x;   // n * channels + c
+  const float* p = sums + plane * slots;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < slots; k += SE_SLICES) s += p[k];
+  partial[plane * SE_SLICES + threadIdx.x] = s;
+}
+
 // one block per n: mean -> fc1 -> relu -> fc2 -> sigmoid
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* partial, int channels, int hidden, float inv_hw,
                                                     const float* fc1, const float* fc2, float* gate) {
@@ -536,6 +547,23 @@ extern "C" int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w,
   int rc = dvc::check_launch("plane_partial_sum_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, x->channels,
+                     hidden, 1.0f / ((float)h * (float)w), fc1, fc2, gate);
+  return dvc::check_launch("se_fc_kernel");
+}
+
+extern "C" int dvc_se_gate_from_sums(const float* sums, int32_t slots, int32_t batch, int32_t channels, int32_t h,
+                                     int32_t w, const float* fc1, const float* fc2, int32_t hidden, float* partial,
+                                     float* gate, void* stream) {
+  static_assert(SE_SLICES == 64, "fold_plane_sums_kernel: one lane per slice");
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && slots >= 1, "dvc_se_gate_from_sums: bad dims");
+  DVC_REQUIRE(channels >= 1 && channels <= 256 && hidden >= 1 && hidden <= 64,
+              "dvc_se_gate_from_sums: channels<=256, hidden<=64 required");
+  DVC_REQUIRE(sums && fc1 && fc2 && partial && gate, "dvc_se_gate_from_sums: null pointer");
+  hipLaunchKernelGGL(fold_plane_sums_kernel, dim3(batch * channels), dim3(64), 0, (hipStream_t)stream, sums, slots,
+                     partial);
+  int rc = dvc::check_launch("fold_plane_sums_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_fc_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float*)partial, channels,
                      hidden, 1.0f / ((float)h * (float)w), fc1, fc2, gate);
   return dvc::check_launch("se_fc_kernel");
 }

@@ -54,7 +54,8 @@ class Conv2d(nn.Module):
         return hit[1]
 
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
-                pixel_shuffle=False, out=None) -> Tensor:
+                pixel_shuffle=False, out=None, plane_sums=False):
+        """`plane_sums=True` (inference only): returns (out, sums), see ops.conv2d."""
         if torch.is_grad_enabled():
             # training path: same forward kernel, on the autograd tape (residual adds un-fused)
             if out is not None:
@@ -65,7 +66,7 @@ class Conv2d(nn.Module):
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
                           pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._precision()),
-                          precision=self._precision())
+                          precision=self._precision(), plane_sums=plane_sums)
 
 
 def conv1x1(in_ch, out_ch, stride=1):
@@ -186,6 +187,10 @@ class SELayer(nn.Module):
             return A.se_gate(x, self.fc[0].weight, self.fc[2].weight)
         return ops.se_gate(x, self.fc[0].weight.detach(), self.fc[2].weight.detach())
 
+    def from_sums(self, sums: Tensor, h: int, w: int) -> Tensor:
+        """The gate from the plane sums the producing convolution emitted with its stores (inference)."""
+        return ops.se_gate_from_sums(sums, h, w, self.fc[0].weight.detach(), self.fc[2].weight.detach())
+
 
 class ConvBlockResidual(nn.Module):
     """up_dim(x) + SE(conv(lrelu(conv(x)))) (reference: layers.py:283-297): three conv launches
@@ -199,8 +204,13 @@ class ConvBlockResidual(nn.Module):
 
     def forward(self, x: Srcs) -> Tensor:
         t = self.conv[0](x, out_slope=0.01)
-        t = self.conv[2](t)
-        gate = self.conv[3](t)
+        if torch.is_grad_enabled():
+            t = self.conv[2](t)
+            gate = self.conv[3](t)
+        else:
+            # the plane means the gate needs come out of the convolution's epilogue where the launch allows
+            t, sums = self.conv[2](t, plane_sums=True)
+            gate = self.conv[3](t) if sums is None else self.conv[3].from_sums(sums, t.size(2), t.size(3))
         return self.up_dim(x, residual=t, res_scale=gate)
 
 

@@ -112,8 +112,11 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
            in_slope: Optional[float] = None, out_slope: Optional[float] = None,
            residual: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
            residual2: Optional[Tensor] = None, pixel_shuffle: bool = False,
-           out: Optional[Tensor] = None, packed: Optional[Tensor] = None, precision: int = 0) -> Tensor:
-    """See DvcConv2d in include/dvc_hip.h.  `precision`: see PRECISIONS; fp32 accumulation in every mode (`packed` must come from
+           out: Optional[Tensor] = None, packed: Optional[Tensor] = None, precision: int = 0,
+           plane_sums: bool = False):
+    """See DvcConv2d in include/dvc_hip.h.  `plane_sums=True` returns (out, sums): where the launch can emit per-tile
+    sums of its output planes with its stores (dvc_conv2d_plane_sum_slots), `sums` is the (N, Cout, slots) tensor
+    se_gate_from_sums() takes, otherwise None (use se_gate on `out`).  `precision`: see PRECISIONS; fp32 accumulation in every mode (`packed` must come from
     pack_conv_weight(..., precision=) with the same value). `srcs` are concatenated along C; slopes of
     None mean "no activation", 0.0 means ReLU.  `weight` is the OIHW tensor (its shape
     describes the layer); `packed` its pack_conv_weight() image -- packed on the fly if
@@ -180,8 +183,14 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
         p.residual2 = residual2.data_ptr()
         p.res2_batch_stride = _bs(residual2)
         p.res2_chan_stride = _cs(residual2)
+    sums = None
+    if plane_sums:
+        slots = check(_lib.load().dvc_conv2d_plane_sum_slots(C.byref(p)), "dvc_conv2d_plane_sum_slots")
+        if slots > 0:
+            sums = torch.empty((n, cout, slots), dtype=torch.float32, device=weight.device)
+            p.plane_sums = sums.data_ptr()
     check(_lib.load().dvc_conv2d(C.byref(p), _stream()), "dvc_conv2d")
-    return out
+    return (out, sums) if plane_sums else out
 
 
 def flow_warp(src: Tensor, flow: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -243,6 +252,25 @@ def se_gate(x: Tensor, fc1: Tensor, fc2: Tensor) -> Tensor:
     gate = torch.empty(n * c, dtype=torch.float32, device=x.device)
     check(lib.dvc_se_gate(C.byref(_src(x)), n, h, w, fc1.data_ptr(), fc2.data_ptr(), fc1.size(0),
                           partial.data_ptr(), gate.data_ptr(), _stream()), "dvc_se_gate")
+    return gate
+
+
+def se_gate_from_sums(sums: Tensor, h: int, w: int, fc1: Tensor, fc2: Tensor) -> Tensor:
+    """se_gate of an (N, C, h, w) tensor whose per-tile plane sums `sums` (N, C, slots) a convolution wrote with
+    its stores (conv2d(..., plane_sums=True)) -> (N*C,) gate."""
+    if sums.dim() != 3:
+        raise ValueError(f"se_gate_from_sums: sums shape {tuple(sums.shape)} is not (N, C, slots)")
+    n, c, slots = sums.shape
+    _check_vec(sums, n * c * slots, "se_gate_from_sums sums")
+    if fc1.dim() != 2 or fc1.size(1) != c or tuple(fc2.shape) != (c, fc1.size(0)):
+        raise ValueError(f"se_gate_from_sums: fc shapes {tuple(fc1.shape)}, {tuple(fc2.shape)} do not match {c} channels")
+    _check_vec(fc1, fc1.size(0) * c, "se_gate_from_sums fc1", device=sums.device)
+    _check_vec(fc2, c * fc1.size(0), "se_gate_from_sums fc2", device=sums.device)
+    lib = _lib.load()
+    partial = torch.empty(lib.dvc_se_scratch_floats(n, c), dtype=torch.float32, device=sums.device)
+    gate = torch.empty(n * c, dtype=torch.float32, device=sums.device)
+    check(lib.dvc_se_gate_from_sums(sums.data_ptr(), slots, n, c, h, w, fc1.data_ptr(), fc2.data_ptr(), fc1.size(0),
+                                    partial.data_ptr(), gate.data_ptr(), _stream()), "dvc_se_gate_from_sums")
     return gate
 
 

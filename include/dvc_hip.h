@@ -96,9 +96,18 @@ typedef struct DvcConv2d {
                                       tensors in every mode); weight_packed must have been packed for the
                                       same mode.  Modes other than FP32 cover ksize 1 and 3 */
   int32_t _pad;
+  float* plane_sums;               /* optional [batch][Cout][dvc_conv2d_plane_sum_slots()]: with its stores, every
+                                      workgroup also writes the sum of the values it stored per output channel --
+                                      the first stage of the plane means the squeeze-excite gate of
+                                      dmc/models/layers.py:267-280 needs (dvc_se_gate_from_sums finishes it), so
+                                      the tensor is not read back for them.  Only where the query below is > 0 */
 } DvcConv2d;
 
 int dvc_conv2d(const DvcConv2d* p, void* stream);
+/* Partial sums per output plane dvc_conv2d(p) writes to p->plane_sums (the value of that field is ignored here):
+ * > 0 for 3x3 stride-1 fp32 launches made of whole tiles, with 16-byte rows and without residual / PixelShuffle;
+ * 0 where the launch cannot emit them (use dvc_se_gate); negative on invalid parameters. */
+int32_t dvc_conv2d_plane_sum_slots(const DvcConv2d* p);
 
 /* Weight layout of the convolution kernel: per block of 64 (Cout > 32) or 32 output
  * channels and per K-chunk of input channels, one contiguous zero-padded slab
@@ -152,6 +161,12 @@ int dvc_spynet_level_input(const DvcSrc* im1, const DvcSrc* im2, const DvcSrc* f
 int64_t dvc_se_scratch_floats(int32_t batch, int32_t channels);
 int dvc_se_gate(const DvcSrc* x, int32_t batch, int32_t h, int32_t w, const float* fc1,
                 const float* fc2, int32_t hidden, float* partial, float* gate, void* stream);
+/* The same gate from plane sums a convolution wrote with its stores (DvcConv2d::plane_sums, `slots` values per
+ * (n, c) plane of h x w pixels): two small launches instead of a pass over the tensor.  Deterministic; the
+ * summation order differs from dvc_se_gate's, so the two agree to rounding, not bit for bit. */
+int dvc_se_gate_from_sums(const float* sums, int32_t slots, int32_t batch, int32_t channels, int32_t h, int32_t w,
+                          const float* fc1, const float* fc2, int32_t hidden, float* partial, float* gate,
+                          void* stream);
 
 /*
  * dvc_se_gate for callers that cannot allocate device memory (code under HIP graph capture, tight

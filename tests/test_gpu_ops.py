@@ -541,3 +541,35 @@ def test_conv2d_7x7_sixteen_channels_row_pairs(cin, H, W, batch, in_slope, out_s
     close(out_big[:, 2:18], want)
     assert torch.equal(out_big[:, 2:18], wide[:, :16]), float((out_big[:, 2:18] - wide[:, :16]).abs().max())
     assert float(out_big[:, :2].abs().max()) == 0.0 and float(out_big[:, 18:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,cout,H,W,batch,out_slope", [
+    (32, 32, 64, 96, 2, None),      # 32-channel blocks
+    (64, 64, 256, 256, 4, None),    # 64-channel blocks, batch
+    (32, 128, 272, 480, 1, 0.01),   # two channel blocks per tile, activation before the sums
+    (64, 64, 544, 960, 1, None),    # 16-row tiles
+])
+def test_conv2d_plane_sums_feed_the_se_gate(cin, cout, H, W, batch, out_slope):
+    """A 3x3 convolution made of whole tiles can emit per-tile sums of its output planes with its stores; the
+    squeeze-excite gate computed from them equals the gate computed by a pass over the stored tensor (to rounding:
+    the two sum in different orders), and the stored tensor itself is unchanged."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = dev(torch.randn(batch, cin, H, W, generator=g))
+    w = dev(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = dev(torch.randn(cout, generator=g))
+    fc1 = dev(torch.randn(cout // 16, cout, generator=g) * 0.3)
+    fc2 = dev(torch.randn(cout, cout // 16, generator=g) * 0.3)
+    plain = ops.conv2d(x, w, b, out_slope=out_slope)
+    out, sums = ops.conv2d(x, w, b, out_slope=out_slope, plane_sums=True)
+    assert sums is not None and sums.shape[:2] == (batch, cout)
+    assert torch.equal(out, plain)
+    close(sums.sum(dim=2), plain.double().sum(dim=(2, 3)).float().cpu(), rel=2e-6)
+    gate = ops.se_gate_from_sums(sums, H, W, fc1, fc2)
+    close(gate, ops.se_gate(plain, fc1, fc2).cpu(), rel=1e-6)
+    # not available: ragged tiles, a residual, a reduced-operand mode -> None, and the plain result
+    y = dev(torch.randn(1, cin, 50, 70, generator=g))
+    o2, s2 = ops.conv2d(y, w, b, plane_sums=True)
+    assert s2 is None and torch.equal(o2, ops.conv2d(y, w, b))
+    o3, s3 = ops.conv2d(x, w, b, residual=plain, plane_sums=True)
+    assert s3 is None
