@@ -19,7 +19,7 @@ def test_ops_match_reference_layers():
     assert torch.equal(O.bilinear_up2(T(g["resample_in"])), T(g["up2_out"]))
     assert torch.equal(O.bilinear_down2(T(g["resample_in"])), T(g["down2_out"]))
     assert torch.equal(O.quantize_ste(T(g["ste_in"])), T(g["ste_out"]))
-    # round half to even (survey probe): .5 -> 0, 1.5 -> 2, 2.5 -> 2, -.5 -> -0
+    # round half to even: .5 -> 0, 1.5 -> 2, 2.5 -> 2, -.5 -> -0
     assert O.quantize_ste(torch.tensor([0.5, 1.5, 2.5, -0.5])).tolist() == [0.0, 2.0, 2.0, -0.0]
 
 

@@ -29,7 +29,7 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    m = re.search(r"conv_mfma_f32_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \w+, \d+)?>", name)
+    m = re.search(r"conv_mfma_f32_kernel<(\d+), (\d+), (\d+), (\d+)(?:, \w+)*>", name)
     if m:
         return "conv_mfma_f32_kernel<%s,%s,%s,%s>" % m.groups()
     m = re.search(r"(\w+_kernel)\b", name)
