@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Free-running parity at the benchmark's size: one 1080p GOP coded by the evaluation loop of dmc/test.py:162-196
+(encode_inter -> decode_inter -> clamp -> buffer update, no teacher forcing) on the GPU product path and,
+independently, on the CPU oracle; prints per-frame bytes / PSNR and the GOP averages with their differences.
+The oracle needs ~12 s per frame on 16 cores (GPU box only; the oracle is the checker, not the product).
+
+    python tools/gop_parity_fullsize.py [--gop 12] [--height 1080 --width 1920] [--precision fp32]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def psnr(x, rec):
+    return -10.0 * math.log10(torch.mean((x.double() - rec.double()) ** 2).item())
+
+
+def code_gop(enc_fn, dec_fn, frames, to_dev, clamp):
+    dpb = {"x_ref": to_dev(frames[0]), "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+    out = []
+    for x in frames[1:]:
+        enc = enc_fn(to_dev(x), dpb)
+        rec, info = dec_fn(enc["strings"], enc["shape"], dpb)
+        rec = clamp(rec)
+        nbytes = sum(len(s[0]) for v in enc["strings"].values() for s in v)
+        out.append((nbytes, psnr(x, rec.cpu()), enc["strings"]))
+        dpb = {"x_ref": rec, "feature_ref": info["feature_ref"], "y_ref": info["y_ref"], "y_mv_ref": info["y_mv_ref"]}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gop", type=int, default=12)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    from deepvideocodec_amd import ops
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import pad_to_multiple, seeded_state_dict, synthetic_gop
+    from oracle import dmc_oracle as O
+
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    sd = seeded_state_dict(seed=0)
+    net = DMC()
+    net.load_state_dict(sd)
+    net = net.to("cuda:0").eval()
+    net.update(force=True)
+    net.set_precision(args.precision)
+    ent = O.EntropyState(sd)
+    ent.update(force=True)
+    frames = [pad_to_multiple(f, 64) for f in synthetic_gop(args.gop, args.height, args.width, seed=args.seed)]
+    n_pix = frames[0].shape[2] * frames[0].shape[3]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        got = code_gop(net.encode_inter, net.decode_inter, frames, lambda t: t.cuda(), lambda t: ops.clamp(t, 0.0, 1.0))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ref = code_gop(lambda x, d: O.encode_inter(sd, ent, x, d), lambda s, sh, d: O.decode_inter(sd, ent, s, sh, d),
+                       frames, lambda t: t, lambda t: t.clamp(0, 1))
+        t2 = time.perf_counter()
+    n = len(got)
+    for i, ((bg, pg, sg), (br, pr, sr)) in enumerate(zip(got, ref), start=1):
+        print(f"frame {i:2d}: bytes {bg:6d} vs {br:6d}, PSNR {pg:.5f} vs {pr:.5f} (d {pg - pr:+.1e}) "
+              f"{'identical streams' if sg == sr else 'streams differ'}", flush=True)
+    bpp_g = 8.0 * sum(b for b, _, _ in got) / (n_pix * n)
+    bpp_r = 8.0 * sum(b for b, _, _ in ref) / (n_pix * n)
+    psnr_g = sum(p for _, p, _ in got) / n
+    psnr_r = sum(p for _, p, _ in ref) / n
+    print(f"GOP {args.gop} at {frames[0].shape[2]}x{frames[0].shape[3]} [{args.precision}], {n} P frames: "
+          f"GPU {bpp_g:.6f} bpp {psnr_g:.5f} dB ({t1 - t0:.1f} s) | oracle {bpp_r:.6f} bpp {psnr_r:.5f} dB ({t2 - t1:.1f} s) | "
+          f"d_bpp {bpp_g - bpp_r:+.2e}, d_PSNR {psnr_g - psnr_r:+.2e} dB")
+
+
+if __name__ == "__main__":
+    main()
