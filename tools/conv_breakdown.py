@@ -1,6 +1,8 @@
 """Per-shape breakdown of the convolution time of one coded P frame pair (encode_inter + decode_inter)
 at 1088x1920: every convolution launch is bracketed with events and tallied by (kernel size, stride,
 Cin, Cout, H, W).  Prints the shapes by share of the total convolution time with their achieved TFLOP/s.
+The decoder's side-stream work is kept on the one stream here, so that no other kernel runs beside a
+bracketed launch (--overlap 1 restores the coding loop's two-stream decoder).
 
     python tools/conv_breakdown.py [--height 1080 --width 1920] [--top 40]
 """
@@ -19,10 +21,11 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--overlap", type=int, default=0)
     args = ap.parse_args()
     from bench import conv_variant
     from deepvideocodec_amd import ops
-    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.models import DMC, video_model
     from deepvideocodec_amd.testing import pad_to_multiple, seeded_state_dict, synthetic_gop
 
     dev = torch.device("cuda:0")
@@ -30,6 +33,8 @@ def main():
     net.load_state_dict(seeded_state_dict(seed=0))
     net = net.to(dev).eval()
     net.update(force=True)
+    if not args.overlap:
+        video_model._DECODE_OVERLAP = False
     frames = [pad_to_multiple(f, 64).to(dev) for f in synthetic_gop(4, args.height, args.width, seed=5)]
     records = []
     orig = ops.conv2d
