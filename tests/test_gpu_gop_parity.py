@@ -34,12 +34,16 @@ def _code_gop(enc_fn, dec_fn, frames, to_dev, clamp):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("gop,size,seed", [(12, 256, 31), (32, 128, 32)])
+@pytest.mark.parametrize("gop,size,seed", [(12, 256, 31), (32, 128, 32), (4, (180, 420), 33)])
 def test_free_running_gop_matches_oracle(gpu_net, seeded_sd, oracle_entropy, gop, size, seed):
     from deepvideocodec_amd import ops
-    from deepvideocodec_amd.testing import synthetic_gop
-    frames = synthetic_gop(gop, size, size, seed=seed)
-    n_pix = size * size
+    from deepvideocodec_amd.testing import pad_to_multiple, synthetic_gop
+    # (a pair: a frame size that is not a multiple of 64, zero-padded as dmc/test.py:75-88 does -- 192 x 448 here,
+    # whose 1/4 .. 1/16 scales leave partial 32-pixel tiles in every convolution variant)
+    h, w = (size, size) if isinstance(size, int) else size
+    frames = [pad_to_multiple(f, 64) for f in synthetic_gop(gop, h, w, seed=seed)]
+    h, w = frames[0].shape[-2:]
+    n_pix = h * w
     with torch.no_grad():
         ref = _code_gop(lambda x, d: O.encode_inter(seeded_sd, oracle_entropy, x, d),
                         lambda s, sh, d: O.decode_inter(seeded_sd, oracle_entropy, s, sh, d), frames, lambda t: t,
@@ -66,7 +70,7 @@ def test_free_running_gop_matches_oracle(gpu_net, seeded_sd, oracle_entropy, gop
                 print("\n".join(lines))
             bpp_g = 8.0 * sum(b for b, _, _ in got) / (n_pix * n)
             psnr_g = sum(p for _, p, _ in got) / n
-            print(f"GOP {gop} at {size}x{size} [{mode}]: GPU {bpp_g:.5f} bpp {psnr_g:.4f} dB | oracle {bpp_r:.5f} bpp "
+            print(f"GOP {gop} at {h}x{w} [{mode}]: GPU {bpp_g:.5f} bpp {psnr_g:.4f} dB | oracle {bpp_r:.5f} bpp "
                   f"{psnr_r:.4f} dB | first differing stream: {first_diff}")
             results[mode] = (bpp_g, psnr_g)
     finally:
