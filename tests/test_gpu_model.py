@@ -164,6 +164,36 @@ def test_forward_vs_oracle_128_batch2(gpu_net, seeded_sd, oracle_entropy):
     assert strict >= 4, f"only {strict} of 6 frame/batch pairs were free of rounding ties ({flips} ties)"
 
 
+def test_codec_batch2_equals_per_sample_coding(gpu_net):
+    """encode_inter / decode_inter on a batch of two sequences: each sample's strings and reconstruction
+    equal, bit for bit, what coding that sequence alone gives (the strings are per sample, as compressai's
+    compress returns them; nothing in the kernels mixes samples)."""
+    from deepvideocodec_amd import ops
+    from deepvideocodec_amd.testing import synthetic_gop
+    frames = [f.cuda() for f in synthetic_gop(3, 128, 192, seed=7, batch=2)]
+
+    def code(fr):
+        dpb = {"x_ref": fr[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
+        out = []
+        for x in fr[1:]:
+            enc = gpu_net.encode_inter(x, dpb)
+            rec, info = gpu_net.decode_inter(enc["strings"], enc["shape"], dpb)
+            out.append((enc["strings"], rec))
+            dpb = {"x_ref": ops.clamp(rec, 0.0, 1.0), "feature_ref": info["feature_ref"], "y_ref": info["y_ref"],
+                   "y_mv_ref": info["y_mv_ref"]}
+        return out
+
+    both = code(frames)
+    for b in range(2):
+        alone = code([f[b:b + 1].contiguous() for f in frames])
+        for i, ((s2, r2), (s1, r1)) in enumerate(zip(both, alone), start=1):
+            for key in s2:
+                assert len(s2[key]) == len(s1[key])
+                for part2, part1 in zip(s2[key], s1[key]):
+                    assert len(part2) == 2 and part2[b] == part1[0], f"sample {b} frame {i}: {key} strings differ"
+            assert torch.equal(r2[b:b + 1], r1), f"sample {b} frame {i}: reconstructions differ"
+
+
 def test_decode_reproduces_encoder_state(gpu_net):
     """The decoder rebuilds exactly the latents the encoder quantised (bit-exact), and
     decode(encode(x)) equals forward()'s reconstruction in eval mode."""
