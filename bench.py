@@ -90,13 +90,15 @@ def codec_gop(net, frames, clamp, reuse=False):
     return nbytes, recs
 
 
-def conv_variant(n, cout, ho, wo, k, stride, thin_ok=False):
+def conv_variant(n, cout, ho, wo, k, stride, thin_ok=False, shuffle=False):
     """(MT, NT) template arguments the library picks for a convolution (the tile is 4*NT x 32
     pixels x 32*MT output channels; NT is the largest of 4/2/1 that still gives >= 512 workgroups,
     3x3 stride-2 layers stop at 2) -- used only to attribute probe timings to kernel names.
     (0, 0) stands for the direct kernel of layers with at most 4 output channels."""
     if thin_ok and cout <= 4 and stride == 1 and k in (3, 7) and n * ((ho + 7) // 8) * ((wo + 31) // 32) >= 256:
         return 0, 0
+    if k == 1 and stride == 1 and not shuffle and (ho * wo) % 32 == 0:
+        ho, wo = ho * wo // 32, 32   # 1x1 stride 1 runs on the plane as rows of 32 pixels
     mt = 2 if cout > 32 else 1
     nt = 2 if (stride == 2 and k != 1) else 4
     cblocks, tx = (cout + 32 * mt - 1) // (32 * mt), (wo + 31) // 32
@@ -144,7 +146,7 @@ class ConvProbe:
             nbytes = 4.0 * (n * cin * h * w + (1 + nres) * n * cout * ho * wo + cout * cin * k * k)
             thin_ok = (len(s) == 1 and not kw.get("pixel_shuffle") and kw.get("res_scale") is None
                        and not kw.get("precision"))
-            mt, nt = conv_variant(n, cout, ho, wo, k, stride, thin_ok)
+            mt, nt = conv_variant(n, cout, ho, wo, k, stride, thin_ok, bool(kw.get("pixel_shuffle")))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = self.orig(srcs, weight, bias, stride=stride, **kw)

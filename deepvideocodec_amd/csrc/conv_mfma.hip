@@ -247,6 +247,17 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
   DVC_REQUIRE(a.plane_sums == nullptr || conv_plane_sum_slots(a, p->ksize, p->stride, p->precision, p->batch) > 0,
               "dvc_conv2d: plane_sums is not available for this launch (dvc_conv2d_plane_sum_slots() == 0)");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->ksize == 1 && p->stride == 1 && !a.ps && ((long long)a.h * a.w) % 32 == 0) {
+    // A 1x1 stride-1 convolution does not see the image's rows: run it on the plane as rows of 32 pixels, so that
+    // a tile (4 NT rows of 32) is one contiguous run of every channel plane instead of 4 NT pieces of 128 bytes a
+    // row pitch apart.  Same products in the same order for every pixel.
+    a.h = a.ho = (int)(((long long)a.h * a.w) / 32);
+    a.w = a.wo = 32;
+    auto al = [](const void* q, long long bs, long long cs) {
+      return reinterpret_cast<uintptr_t>(q) % 16 == 0 && bs % 4 == 0 && cs % 4 == 0;
+    };
+    a.vec4 = al(a.out, a.obs, a.ocs) && (!a.res || al(a.res, a.rbs, a.rcs)) && (!a.res2 || al(a.res2, a.r2bs, a.r2cs));
+  }
   if (p->precision != DVC_PRECISION_FP32) {
     DVC_REQUIRE(p->ksize != 7 && p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,
                 "dvc_conv2d: precision %d unknown, or a reduced-operand mode with ksize 7", p->precision);

@@ -44,6 +44,8 @@ CONV_CASES = [
     (1, 2, (2,), 64, 32, 48, 1),
     (1, 2, (64,), 64, 34, 50, 2),
     (1, 1, (32, 32), 64, 64, 64, 1),
+    (1, 1, (64,), 64, 32, 47, 1),       # H*W = 47 rows of 32: the 1x1 kernel's rows of 32 cross the image's rows
+    (1, 1, (16, 48), 32, 24, 20, 2),    # 15 rows of 32: a partial tile
     (3, 1, (5, 7, 9, 11), 40, 21, 19, 1),
 ]
 
@@ -107,6 +109,29 @@ def test_conv2d_epilogues():
     want = F.pixel_shuffle(F.conv2d(x, w1, b1), 2) + rs
     got = ops.conv2d(dev(x), dev(w1), dev(b1), pixel_shuffle=True, residual=dev(rs))
     close(got, want)
+
+
+@pytest.mark.parametrize("H,W", [(24, 44), (16, 50), (15, 20), (272, 480)])
+def test_conv2d_1x1_on_the_flattened_plane(H, W):
+    """1x1 stride 1 runs on the plane as rows of 32 pixels when H*W is a multiple of 32 (15 x 20 is not): input and
+    output activations, scaled residual and second residual, sources / residuals / destination as channel slices of
+    larger buffers, and nothing written around the destination."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(H * 7 + W)
+    big = torch.randn(2, 96, H, W, generator=g)
+    x1, x2 = big[:, 4:52], big[:, 60:76]        # 48 + 16 channels
+    w = torch.randn(64, 64, 1, 1, generator=g) / 8
+    b = torch.randn(64, generator=g)
+    rbig = torch.randn(2, 160, H, W, generator=g)
+    r1, r2 = rbig[:, 8:72], rbig[:, 80:144]
+    sc = torch.rand(2, 64, generator=g)
+    want = (F.leaky_relu(F.conv2d(F.leaky_relu(torch.cat([x1, x2], 1), 0.01), w, b), 0.1) + r1 * sc[:, :, None, None]) + r2
+    dbig, drbig = dev(big), dev(rbig)
+    buf = torch.full((2, 80, H, W), 7.5, device="cuda:0")
+    got = ops.conv2d([dbig[:, 4:52], dbig[:, 60:76]], dev(w), dev(b), in_slope=0.01, out_slope=0.1,
+                     residual=drbig[:, 8:72], res_scale=dev(sc).reshape(-1), residual2=drbig[:, 80:144], out=buf[:, 8:72])
+    close(got, want)
+    assert float((buf[:, :8] - 7.5).abs().max()) == 0.0 and float((buf[:, 72:] - 7.5).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (6, 10), (7, 7), (8, 12), (17, 30), (5, 64)])

@@ -49,7 +49,7 @@ def main():
         ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
         thin_ok = (len(s) == 1 and not kw.get("pixel_shuffle") and kw.get("res_scale") is None
                    and not kw.get("precision"))
-        mt, nt = conv_variant(n, cout, ho, wo, k, stride, thin_ok)
+        mt, nt = conv_variant(n, cout, ho, wo, k, stride, thin_ok, bool(kw.get("pixel_shuffle")))
         extras = "".join(c for c, on in (("c", len(s) > 1), ("r", kw.get("residual") is not None),
                                          ("R", kw.get("residual2") is not None), ("g", kw.get("res_scale") is not None),
                                          ("p", bool(kw.get("pixel_shuffle")))) if on)
