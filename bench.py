@@ -63,9 +63,13 @@ def parse():
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
                          "not the headline configuration")
-    ap.add_argument("--gops-in-flight", type=int, default=3,
+    ap.add_argument("--training", type=int, default=1,
+                    help="1: after the coding legs, also time the training step of dmc/train.py:285-346 (batch 32 per GPU, "
+                         "256x256 crops, T=3, joint stage; 1 warm-up + 3 steps) and report it as `training`; 0 skips it")
+    ap.add_argument("--gops-in-flight", type=int, default=None,
                     help="independent GOPs coded concurrently per GPU (one host thread + HIP stream each); "
-                         "a step codes this many GOPs per GPU")
+                         "a step codes this many GOPs per GPU.  Default: 3 where the rank has six or more host "
+                         "cores to itself (cpus allowed / ranks of the node), fewer otherwise")
     return ap.parse_args()
 
 
@@ -112,14 +116,21 @@ def conv_variant(n, cout, ho, wo, k, stride, thin_ok=False, shuffle=False):
 def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the newest committed counter summary
     (profiles/r*_pmc_traffic.json, written by tools/pmc_summary.py from separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command); None when there is none."""
+    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command) with where it came from;
+    (None, None) when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        rec = json.load(f).get("kernels", {}).get(kernel)
-    return None if rec is None else rec["traffic_bytes_per_launch"]
+        doc = json.load(f)
+    rec = doc.get("kernels", {}).get(kernel)
+    if rec is None:
+        return None, None
+    return rec["traffic_bytes_per_launch"], {"file": os.path.relpath(files[-1], ROOT), "command": doc.get("command"),
+                                             "note": "read from this committed counter summary (separate rocprofv3 --pmc "
+                                                     "FETCH_SIZE / WRITE_SIZE passes, FETCH doubled for gfx950), not "
+                                                     "measured in this run"}
 
 
 class ConvProbe:
@@ -269,6 +280,92 @@ def pad64(v):
     return (v + 63) // 64 * 64
 
 
+def _coder_pool_workers():
+    from deepvideocodec_amd.models import video_model
+    return video_model._POOL._max_workers
+
+
+PEAK_MFMA16_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 matrix peak
+
+
+def reduced_roofline(mode, probe):
+    """Roofline of the 16-bit-operand modes from a probed frame pair: the dominant convolution variant and all
+    convolution launches together, against both roofs that can bound them -- algorithmic bytes (fp32 tensors in
+    HBM: inputs, residuals, outputs, weights, each once) per second against the HBM peak, and issued 16-bit MFMA
+    FLOPs (3 products per term for the hi + lo split modes, 1 for bf16) against the dense 16-bit matrix peak.  The
+    7x7 motion-estimation layers stay exact fp32 in every mode and are listed separately."""
+    if probe is None:
+        return None
+    per = probe.summary()
+    issued = 3.0 if mode in ("fp16x2", "bf16x2") else 1.0
+    red = {k: v for k, v in per.items() if k[0] != 7 and k[2] != 0}     # 1x1 / 3x3 on the 16-bit MFMA
+    f32 = {k: v for k, v in per.items() if k not in red}                # 7x7 layers, <= 4-output-channel layers
+    if not red:
+        return None
+    (k, st, mt, nt), (fl, tm, cnt, nb) = max(red.items(), key=lambda kv: kv[1][1])
+    rfl, rtm, rnb = (sum(v[i] for v in red.values()) for i in (0, 1, 3))
+    ffl, ftm = (sum(v[i] for v in f32.values()) for i in (0, 1))
+    def both(fl_, nb_, tm_):
+        return {"hbm": {"achieved": nb_ / tm_ / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nb_ / tm_ / 1e9 / PEAK_HBM_GBS},
+                "mfma16": {"achieved": issued * fl_ / tm_ / 1e12, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s issued",
+                           "frac": issued * fl_ / tm_ / 1e12 / PEAK_MFMA16_TFLOPS,
+                           "algorithmic_tflops": fl_ / tm_ / 1e12}}
+    out = {"bound": "hbm", "kernel": f"conv_mfma_f32_kernel<{k},{st},{mt},{nt}> ({mode} operands)", "launches": cnt,
+           "avg_launch_ms": tm / cnt * 1e3, "algorithmic_bytes_per_launch": nb / cnt, "gflop_per_launch": fl / cnt / 1e9}
+    out.update(both(fl, nb, tm))
+    out["achieved"], out["peak"], out["unit"], out["frac"] = (out["hbm"]["achieved"], PEAK_HBM_GBS, "GB/s", out["hbm"]["frac"])
+    out["all_reduced_convs"] = dict(both(rfl, rnb, rtm), ms_per_frame=rtm / 2 * 1e3)
+    out["fp32_convs_left"] = {"ms_per_frame": ftm / 2 * 1e3, "achieved": ffl / max(ftm, 1e-12) / 1e12, "unit": "TFLOP/s",
+                              "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ffl / max(ftm, 1e-12) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    out["hbm_bound_kernels"] = probe.hbm_summary()
+    return out
+
+
+def training_leg(dev, world, rank, barrier, batch=32, size=256, frames=3, warmup=1, steps=3):
+    """One GPU's share of the reference's training workload (dmc/train.sh:3-9, dmc/train.py:285-346): batch 32 of
+    T=3 random 256 x 256 crops, joint stage (epoch >= 40), lambda 2048, Adam 1e-4 / aux 1e-3, clip 1.0.  With more
+    than one rank the gradients are averaged by bucketed all-reduces before the optimizer steps."""
+    from deepvideocodec_amd import train as TR
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import seeded_state_dict, synthetic_gop
+    net = DMC()
+    net.load_state_dict(seeded_state_dict(seed=0))
+    net = net.to(dev).train()
+    crit = TR.RateDistortionLoss(lmbda=2048.0)
+    opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
+    batches = [[f.to(dev) for f in synthetic_gop(frames, size, size, seed=rank * 100 + s, batch=batch)]
+               for s in range(warmup + steps)]
+    torch.cuda.reset_peak_memory_stats(dev)
+    stats = None
+    for s in range(warmup):
+        stats = TR.train_step(net, crit, batches[s], opt, aux_opt, 1.0, 45)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        stats = TR.train_step(net, crit, batches[s], opt, aux_opt, 1.0, 45)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    # forward FLOPs of one P frame at 256 x 256: 0.2169 TFLOP; backward = data + weight gradient = 2x forward
+    fwd_tflop = 0.2169 * (size * size) / (256.0 * 256.0) * (frames - 1) * batch
+    tf = 3 * fwd_tflop / (el / steps)
+    mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del net, opt, aux_opt, batches
+    torch.cuda.empty_cache()
+    return {"workload": f"train_step, batch {batch} per GPU x {world} GPU(s), T={frames}, {size}x{size} crops, joint stage, "
+                        "lambda 2048, Adam + aux Adam, clip 1.0" + (", gradients all-reduced (RCCL)" if world > 1 else ""),
+            "value": batch * world * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "warmup": warmup, "global_batch": batch * world, "dtype": "f32",
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                         "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                         "flops": "3 x forward algorithmic FLOPs (forward + data gradient + weight gradient)"},
+            "max_mem_gb": mem, "last_step": stats}
+
+
 def dry_run(args, world, rank):
     """The multi-rank skeleton of main() without a GPU: same GOP numbering, barriers and timing
     reduction, gloo instead of RCCL.  Rank 0 prints the JSON line with the ranks that took part."""
@@ -313,6 +410,8 @@ def main():
     world = launch.resolve_world(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_devices=not args.dry_run)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gops_in_flight is None:
+        args.gops_in_flight = launch.default_gops_in_flight(launch.host_budget()["cores_per_rank"])
     if args.dry_run:
         return dry_run(args, world, rank)
     dev = torch.device("cuda", local_rank)
@@ -369,6 +468,7 @@ def main():
         run_step(s)
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     total_bytes = 0
     last_recs = None
     for s in range(args.warmup, args.warmup + args.steps):
@@ -376,6 +476,16 @@ def main():
         total_bytes += b
     barrier()
     elapsed = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
+    import threading
+    budget = launch.host_budget()
+    host = {"process_cpu_s_per_frame": cpu_s / (n_p * args.steps * G), "host_cores_busy": cpu_s / elapsed,
+            "threads": threading.active_count(), "coder_pool_workers": _coder_pool_workers(),
+            "gop_threads": G, "cpu_count": os.cpu_count(), "cpus_allowed": budget["cpus_allowed"],
+            "local_world_size": budget["local_world"], "cores_per_rank_budget": budget["cores_per_rank"],
+            "note": "rank 0's process over the timed region: CPU seconds (all threads: GOP threads launching kernels "
+                    "through ctypes, range-coder pool) per coded P frame, and their ratio to wall time = host cores "
+                    "kept busy per rank"}
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -400,15 +510,14 @@ def main():
 
     # ---- roofline of the convolution engine: one probed GOP frame pair (untimed), taken right after the timed
     # region, in the state the timed steps left the GPU in
-    probe = None
-    if rank == 0:
+    def probe_frame_pair():
         last = gops[args.warmup + args.steps - 1][0]
         from deepvideocodec_amd.models import video_model as _vm
         lookahead, overlap = net.decode_lookahead, _vm._DECODE_OVERLAP
         if not args.probe_overlap:
             net.decode_lookahead, _vm._DECODE_OVERLAP = False, False
         try:
-            with ConvProbe() as probe:
+            with ConvProbe() as pr:
                 dpb = {"x_ref": last[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
                 for x in last[1:3]:
                     enc = net.encode_inter(x, dpb)
@@ -417,6 +526,9 @@ def main():
                            "y_mv_ref": info["y_mv_ref"]}
         finally:
             net.decode_lookahead, _vm._DECODE_OVERLAP = lookahead, overlap
+        return pr
+
+    probe = probe_frame_pair() if rank == 0 else None
 
     # ---- the same steps once more per reduced-operand mode (reported beside the headline, never as it)
     alts = []
@@ -439,8 +551,14 @@ def main():
                 tt = torch.tensor([alt_elapsed], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 alt_elapsed = tt.item()
-            alts.append((mode, alt_elapsed, alt_bytes, alt_recs))
+            alts.append((mode, alt_elapsed, alt_bytes, alt_recs, probe_frame_pair() if rank == 0 else None))
         net.set_precision("fp32")
+
+    # ---- the training step of dmc/train.py:285-346 at the reference's stated size (batch 32 per GPU, 256 x 256 crops,
+    # T = 3, joint stage): every rank steps, gradients are averaged over ranks (RCCL) when there is more than one
+    training = None
+    if args.training:
+        training = training_leg(dev, world, rank, barrier)
 
     out = None
     if rank == 0:
@@ -462,7 +580,7 @@ def main():
                     "(up to 7e-3 dB against the CPU oracle), deviations average out over a GOP",
         }
         alt_outs = []
-        for mode, alt_elapsed, alt_bytes, alt_recs in alts:
+        for mode, alt_elapsed, alt_bytes, alt_recs, alt_probe in alts:
             alt_psnrs = []
             for x, r in zip(last[1:], alt_recs):
                 sse = ops.sq_err_sum(crop_to(x, (args.height, args.width)).contiguous(),
@@ -474,6 +592,7 @@ def main():
                              "psnr_db": sum(alt_psnrs) / len(alt_psnrs),
                              "d_bpp_vs_fp32": alt_bpp - bpp,
                              "d_psnr_db_vs_fp32": sum(alt_psnrs) / len(alt_psnrs) - sum(psnrs) / len(psnrs),
+                             "roofline": reduced_roofline(mode, alt_probe),
                              "note": "same steps and GOPs as the headline; " + alt_notes.get(mode, "")})
 
         per = probe.summary()
@@ -482,9 +601,10 @@ def main():
         all_time = sum(v[1] for v in per.values())
         (k, st, mt, nt), (fl, tm, cnt, nb) = dom
         kname = f"conv_mfma_f32_kernel<{k},{st},{mt},{nt}>"
+        traffic, traffic_source = measured_traffic(kname)
         roof = {"bound": "mfma", "kernel": kname,
                 "achieved": fl / tm / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": fl / tm / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(kname),
+                "frac": fl / tm / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "launches": cnt, "avg_launch_ms": tm / cnt * 1e3, "gflop_per_launch": fl / cnt / 1e9,
                 "algorithmic_bytes_per_launch": nb / cnt,
                 "hbm_bound_kernels": probe.hbm_summary(),
@@ -513,7 +633,10 @@ def main():
             "bpp": bpp, "psnr_db": sum(psnrs) / len(psnrs),
             "single_stream_fps": single_fps,
             "roofline": roof,
+            "host": host,
         }
+        if training is not None:
+            out["training"] = training
         if alt_outs:
             out["alt_precision"] = alt_outs[0]
             if len(alt_outs) > 1:

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dvc_eb_forward": (C.c_int, [_SRC, _P, _P, _P, _DST, _DST, _P, _i32, _i32, _i32, _P]),
     "dvc_eb_dequantize": (C.c_int, [_P, _P, _DST, _i32, _i32, _i32, _i32, _P]),
     "dvc_dual_prior_pass1": (C.c_int, [_SRC, _SRC, _SRC, _DST, _i32, _i32, _i32, _P]),
+    "dvc_process_with_mask": (C.c_int, [_SRC, _SRC, _SRC, _P, _DST, _DST, _DST, _DST, _i32, _i32, _i32, _P]),
     "dvc_dual_prior_pass2": (C.c_int, [_SRC, _SRC, _SRC, _SRC, _P, _DST, _DST, _DST, _DST, _P, _P, _P, _i32,
                                         _i32, _i32, _i32, _P]),
     "dvc_dual_prior_dec_indexes": (C.c_int, [_SRC, _i32, _P, _P, _i32, _i32, _i32, _i32, _i32, _P]),

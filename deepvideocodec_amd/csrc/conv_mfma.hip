@@ -269,7 +269,8 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
                          : dvc::conv_mfma_run_p3_k1(a, 1, p->stride, p->batch, st);
   }
   // a handful of output channels would leave 28+ of the 32 MFMA rows idle: plain FMAs on the vector ALUs
-  if (dvc::thin_conv_applies(a, p->ksize, p->stride, p->batch)) return dvc::launch_thin_conv(a, p->ksize, p->batch, st);
+  if (a.plane_sums == nullptr && dvc::thin_conv_applies(a, p->ksize, p->stride, p->batch))
+    return dvc::launch_thin_conv(a, p->ksize, p->batch, st);
   if (p->ksize == 3)
     return p->stride == 1 ? dvc::conv_mfma_run_f32_k3s1(a, 3, 1, p->batch, st) : dvc::conv_mfma_run_f32_k3s2(a, 3, 2, p->batch, st);
   if (p->ksize == 1) return dvc::conv_mfma_run_f32_k1(a, 1, p->stride, p->batch, st);

@@ -1044,13 +1044,16 @@ inline int launch_rowpair(const ConvArgs& a, int batch, hipStream_t st) {
 // Partial sums per output plane that a 3x3 stride-1 fp32 launch can emit with its stores (ConvArgs::plane_sums):
 // one per workgroup tile, when the launch is made of whole tiles of the variant dispatch_tile<3, 1, 0> picks, has
 // 16-byte rows, no residual and no PixelShuffle.  0: not available for this launch.
-inline int conv_plane_sum_slots(const ConvArgs& a, int ksize, int stride, int precision, int batch) {
+// The tile height (and with it whether sums are available, how many slots there are and in which order the
+// pixels of a plane are added up) is chosen from ONE sample's tile count, whatever the batch: the sums of a
+// sample -- and the gate, and everything downstream of it -- are then the same bits whether the sample is
+// coded alone or inside a batch (a stream coded as a batch must decode per sample).
+inline int conv_plane_sum_slots(const ConvArgs& a, int ksize, int stride, int precision, int /*batch*/) {
   if (precision != 0 || ksize != 3 || stride != 1 || a.ps || !a.vec4 || a.res != nullptr || a.out_slope < 0.f ||
-      a.out_slope > 1.f || dvc::thin_conv_applies(a, ksize, stride, batch))
+      a.out_slope > 1.f || a.cout <= 4)
     return 0;
   const int mt = a.cout > 32 ? 2 : 1;
-  const int nt = pick_nt(a, batch, mt, 4);
-  if (mt == 2 && nt == 1) return 0;   // (small launches: half blocks / 4-row tiles, not covered)
+  const int nt = pick_nt(a, 1, mt, 4);
   if (a.cout % (32 * mt) != 0 || a.ho % (4 * nt) != 0 || a.wo % 32 != 0) return 0;
   const long long slots = (long long)(a.ho / (4 * nt)) * (a.wo / 32);
   return slots <= 65536 ? (int)slots : 0;
@@ -1063,13 +1066,14 @@ int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   // workgroups per CU, so those stop at 8 rows
   // (the split-operand 3x3 kernels hold two parts of every operand: 64 channels x 16 rows would spill)
   constexpr bool WIDE_OK = !(S == 2 && KS != 1) && !(BF >= 2 && KS == 3);
-  const int nt = pick_nt(a, batch, mt, S == 2 && KS != 1 ? 2 : (mt == 2 && !WIDE_OK) ? 2 : 4);
+  // (a launch that emits plane sums picks its tile from one sample's tile count: see conv_plane_sum_slots)
+  const int nt = pick_nt(a, a.plane_sums != nullptr ? 1 : batch, mt, S == 2 && KS != 1 ? 2 : (mt == 2 && !WIDE_OK) ? 2 : 4);
   if (mt == 2) {
     if (nt == 4) { if constexpr (WIDE_OK) return launch<KS, S, 2, 4, false, BF>(a, batch, st); }
     if (nt == 2) return launch<KS, S, 2, 2, false, BF>(a, batch, st);
     // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
     const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
-    if (blocks < 384) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
+    if (blocks < 384 && a.plane_sums == nullptr) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
     return launch<KS, S, 2, 1, false, BF>(a, batch, st);
   }
   if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4, false, BF>(a, batch, st); }

@@ -229,6 +229,29 @@ __global__ __launch_bounds__(256) void dec_apply_kernel(const int* symbols, Src 
   }
 }
 
+// process_with_mask of the reference (video_model.py:161-167) for an arbitrary (h, w) mask plane shared by every
+// sample and channel: means_hat = mu * m, scales_hat = sigma * m, y_quant = round((y - means_hat) * m),
+// y_hat = y_quant + means_hat
+__global__ __launch_bounds__(256) void process_with_mask_kernel(Src y, Src means, Src scales, const float* mask, Dst y_quant,
+                                                                Dst y_hat, Dst means_hat, Dst scales_hat, int batch, int h,
+                                                                int w) {
+  const int C = y.c;
+  const long long hw = (long long)h * w, total = hw * C * batch;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i % hw;
+    long long t = i / hw;
+    const int c = (int)(t % C), n = (int)(t / C);
+    const float m = mask[pix];
+    const float mh = __fmul_rn(means.p[n * means.bs + c * means.cs + pix], m);
+    const float sh = __fmul_rn(scales.p[n * scales.bs + c * scales.cs + pix], m);
+    const float q = rintf(__fmul_rn(__fsub_rn(y.p[n * y.bs + c * y.cs + pix], mh), m));
+    if (y_quant.p) y_quant.p[n * y_quant.bs + c * y_quant.cs + pix] = q;
+    if (y_hat.p) y_hat.p[n * y_hat.bs + c * y_hat.cs + pix] = __fadd_rn(q, mh);
+    if (means_hat.p) means_hat.p[n * means_hat.bs + c * means_hat.cs + pix] = mh;
+    if (scales_hat.p) scales_hat.p[n * scales_hat.bs + c * scales_hat.cs + pix] = sh;
+  }
+}
+
 // stand-alone Gaussian conditional (compressai GaussianConditional.forward): outputs and likelihood
 __global__ __launch_bounds__(256) void gaussian_conditional_kernel(Src x, Src scales, Src means, const float* noise,
                                                                    Dst outputs, Dst lik, int batch, int h, int w) {
@@ -371,6 +394,25 @@ extern "C" int dvc_dual_prior_pass1(const DvcSrc* y, const DvcSrc* means, const 
   hipLaunchKernelGGL(dual_prior_pass1_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(y),
                      mk(means), mk(scales), mk(yhat1), batch, h, w);
   return dvc::check_launch("dual_prior_pass1_kernel");
+}
+
+extern "C" int dvc_process_with_mask(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales, const float* mask,
+                                     const DvcDst* y_quant, const DvcDst* y_hat, const DvcDst* means_hat,
+                                     const DvcDst* scales_hat, int32_t batch, int32_t h, int32_t w, void* stream) {
+  DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_process_with_mask: bad dims");
+  DVC_TRY(check_plane(y, h, w, "dvc_process_with_mask(y)"));
+  DVC_TRY(check_plane(means, h, w, "dvc_process_with_mask(means)"));
+  DVC_TRY(check_plane(scales, h, w, "dvc_process_with_mask(scales)"));
+  DVC_REQUIRE(means->channels == y->channels && scales->channels == y->channels, "dvc_process_with_mask: channel mismatch");
+  DVC_REQUIRE(mask != nullptr, "dvc_process_with_mask: null mask");
+  DVC_TRY(check_dst_opt(y_quant, h, w, "dvc_process_with_mask(y_quant)"));
+  DVC_TRY(check_dst_opt(y_hat, h, w, "dvc_process_with_mask(y_hat)"));
+  DVC_TRY(check_dst_opt(means_hat, h, w, "dvc_process_with_mask(means_hat)"));
+  DVC_TRY(check_dst_opt(scales_hat, h, w, "dvc_process_with_mask(scales_hat)"));
+  const long long total = (long long)batch * y->channels * h * w;
+  hipLaunchKernelGGL(process_with_mask_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, mk(y),
+                     mk(means), mk(scales), mask, mk(y_quant), mk(y_hat), mk(means_hat), mk(scales_hat), batch, h, w);
+  return dvc::check_launch("process_with_mask_kernel");
 }
 
 extern "C" int dvc_dual_prior_pass2(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales, const DvcSrc* spatial,

@@ -102,15 +102,20 @@ def evaluate_sequence(net, frames: Sequence[torch.Tensor], gop: int = 32, intra:
         clamp = lambda t: t.clamp(0, 1)
     ranges = sharding.gop_ranges(len(frames), gop)
     segments, nbytes, sum_psnr, count = [], 0, 0.0, 0
-    if hasattr(net, "decode_lookahead"):
+    had_lookahead = getattr(net, "decode_lookahead", None)
+    if had_lookahead is not None:
         net.decode_lookahead = True        # code_gop decodes every frame right after encoding it
-    with torch.no_grad():
-        for g in sharding.gops_of_rank(len(ranges), rank, world):
-            s, e = ranges[g]
-            fd = io.BytesIO()
-            b, p, c = code_gop(net, frames[s:e], fd, intra, clamp)
-            segments.append((g, fd.getvalue()))
-            nbytes, sum_psnr, count = nbytes + b, sum_psnr + p, count + c
+    try:
+        with torch.no_grad():
+            for g in sharding.gops_of_rank(len(ranges), rank, world):
+                s, e = ranges[g]
+                fd = io.BytesIO()
+                b, p, c = code_gop(net, frames[s:e], fd, intra, clamp)
+                segments.append((g, fd.getvalue()))
+                nbytes, sum_psnr, count = nbytes + b, sum_psnr + p, count + c
+    finally:
+        if had_lookahead is not None:      # the caller's setting comes back, whatever happened
+            net.decode_lookahead = had_lookahead
     dev = frames[0].device if frames[0].is_cuda else None
     nbytes, sum_psnr, count = sharding.reduce_stats(nbytes, sum_psnr, count, device=dev)
     h, w = frames[0].size(2), frames[0].size(3)

@@ -50,7 +50,7 @@ def resolve_world(gpus: Optional[int], script: str, argv: List[str], need_device
         raise WorldError(f"--gpus {gpus}")
     if need_devices:
         import torch
-        have = torch.cuda.device_count()   # counts devices without initialising the GPU runtime
+        have = torch.cuda.device_count()   # (this parent only ever starts a child process: it never launches GPU work)
         if have < gpus:
             raise WorldError(f"--gpus {gpus} but only {have} GPU(s) are visible")
     sys.exit(_launch(gpus, script, argv))
@@ -83,6 +83,36 @@ def _launch(gpus: int, script: str, argv: List[str]) -> int:
         print(f"launch: asked for {gpus} ranks, the result reports n_gpus={results[0].get('n_gpus')}", file=sys.stderr)
         return 4
     return 0
+
+
+def host_budget() -> dict:
+    """Host cores this rank may count on: the CPUs the process is allowed to run on (capped by OMP_NUM_THREADS
+    where the environment sets one as the job's CPU share), divided by the ranks of this node."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    per_rank = max(1, allowed // local_world)
+    try:
+        omp = int(os.environ["OMP_NUM_THREADS"])
+        if omp >= 2:      # (torch.distributed.run exports 1 when the variable is unset: not a statement about the host)
+            per_rank = min(per_rank, omp)
+    except (KeyError, ValueError):
+        pass
+    return {"cpus_allowed": allowed, "local_world": local_world, "cores_per_rank": per_rank}
+
+
+def default_gops_in_flight(cores_per_rank: int) -> int:
+    """Independent GOPs coded concurrently per GPU (one host thread + stream each, sharing a range-coder pool):
+    three hide the decoder's host round trips completely and keep about two host cores busy (bench.py's `host`
+    block); fewer where a rank has fewer than six cores to itself."""
+    return 3 if cores_per_rank >= 6 else 2 if cores_per_rank >= 3 else 1
+
+
+def coder_pool_workers(cores_per_rank: int) -> int:
+    """Threads of the range-coder pool of one rank: a frame has six symbol streams, so six at most."""
+    return max(2, min(6, cores_per_rank - 2))
 
 
 def init_process_group(world: int, backend: str, device=None):

@@ -32,7 +32,9 @@ from .layers import (ConvStack3, Conv2d, Indexed, ME_Spynet, ResBlock, UNet, bil
 from .utils import resize_registered_buffers
 
 Tensor = torch.Tensor
-_POOL = ThreadPoolExecutor(max_workers=6)
+# host threads that range-code the symbol streams (six per frame), sized to this rank's share of the host cores
+from ..launch import coder_pool_workers, host_budget  # noqa: E402
+_POOL = ThreadPoolExecutor(max_workers=coder_pool_workers(host_budget()["cores_per_rank"]))
 # DVC_DECODE_OVERLAP=0 keeps decode_inter on one stream (for measuring what the overlap buys)
 _DECODE_OVERLAP = os.environ.get("DVC_DECODE_OVERLAP", "1") != "0"
 
@@ -246,6 +248,9 @@ class _DualPriorContextModel(CompressionModel):
     (reference: video_model.py:152-291 and its verbatim twin :324-466)."""
 
     latent_channels: int
+    # a dict set by a test receives the latent, its predicted means and the hyper-latent of the next inference
+    # forward() (the values the quantisers see); None in normal operation
+    trace: Optional[dict] = None
 
     @staticmethod
     def get_mask(height, width, device):
@@ -255,6 +260,34 @@ class _DualPriorContextModel(CompressionModel):
         jj = torch.arange(width, device=device).view(1, width)
         mask_0 = (((ii + jj) % 2) == 0).float().view(1, 1, height, width)
         return mask_0, 1.0 - mask_0
+
+    @torch.no_grad()
+    def process_with_mask(self, y, means, scales, mask):
+        """reference: video_model.py:161-167 -> (y_quant, y_hat, means_hat, scales_hat).  The coding path does not
+        call this (its two checkerboard passes are fused kernels); kept for callers of the reference's helper."""
+        return ops.process_with_mask(y, means, scales, mask.contiguous())
+
+    @torch.no_grad()
+    def forward_dual_prior(self, y, means, scales, mode="trainval"):
+        """reference: video_model.py:169-216, same return structure: (y_hat, means_hat, scales_hat), or with
+        mode='compress' (y_hat, y_quant_w_0, y_quant_w_1, scales_w_0, scales_w_1) where the w_0 / w_1 planes hold
+        channel half 0 on even / odd sites and half 1 on odd / even sites.  Inference only (the differentiable
+        form is forward())."""
+        _, _, h, w = y.shape
+        mask_0, mask_1 = self.get_mask(h, w, y.device)
+        y_0, y_1 = y.chunk(2, 1)           # (channel-slice views: the kernels take strided planes)
+        m_0, m_1 = means.chunk(2, 1)
+        s_0, s_1 = scales.chunk(2, 1)
+        q00, yh00, mh00, sh00 = ops.process_with_mask(y_0, m_0, s_0, mask_0)
+        q11, yh11, mh11, sh11 = ops.process_with_mask(y_1, m_1, s_1, mask_1)
+        m_0, s_0, m_1, s_1 = self.y_spatial_prior((yh00, yh11, means, scales)).chunk(4, 1)
+        q01, yh01, mh01, sh01 = ops.process_with_mask(y_0, m_0, s_0, mask_1)
+        q10, yh10, mh10, sh10 = ops.process_with_mask(y_1, m_1, s_1, mask_0)
+        add = ops.add_scaled
+        y_hat = torch.cat((add(yh00, yh01), add(yh11, yh10)), 1)
+        if mode == "compress":
+            return y_hat, add(q00, q11), add(q01, q10), add(sh00, sh11), add(sh01, sh10)
+        return y_hat, torch.cat((add(mh00, mh01), add(mh11, mh10)), 1), torch.cat((add(sh00, sh01), add(sh11, sh10)), 1)
 
     def _prior_params(self, z_hat: Tensor, y_ref: Optional[Tensor], context: Optional[Tensor]):
         raise NotImplementedError
@@ -291,7 +324,10 @@ class _DualPriorContextModel(CompressionModel):
         if grad:
             y_hat, y_likelihoods = A.dual_prior_pass2(y, means, scales, spatial, noise)
             return y_hat, {"y": y_likelihoods, "z": z_likelihoods}
-        r = ops.dual_prior_pass2(y, means, scales, spatial, noise=noise, want=("y_hat", "likelihood"))
+        want = ("y_hat", "likelihood") if self.trace is None else ("y_hat", "likelihood", "means_hat")
+        r = ops.dual_prior_pass2(y, means, scales, spatial, noise=noise, want=want)
+        if self.trace is not None:   # what the quantiser saw (parity tests compare pre-rounding values)
+            self.trace.update(y=y, means_hat=r["means_hat"], z=z)
         return r["y_hat"], {"y": r["likelihood"], "z": z_likelihoods}
 
     def _compress_device(self, y, y_ref, context):
@@ -500,6 +536,7 @@ class DMC(nn.Module):
         mcm, fcm = self.motion_context_model, self.frame_context_model
         mcm.gaussian_conditional.coder_tables(), fcm.gaussian_conditional.coder_tables()
         mcm.entropy_bottleneck.coder_tables(), fcm.entropy_bottleneck.coder_tables()
+        self._take_lookahead({"x_ref": None, "feature_ref": None})   # drop what an undecoded frame left behind
         mv = self.optic_flow(x_cur, dpb["x_ref"])
         y_mv = self.motion_encoder(mv)
         y_mv_hat, mv_pending = mcm._compress_device(y_mv, dpb["y_mv_ref"], None)
@@ -589,6 +626,7 @@ class DMC(nn.Module):
 
     def _take_lookahead(self, dpb):
         import threading
+        # (popped whether it matches or not: a stale entry must neither pin GPU memory nor meet a later frame)
         hit = self.__dict__.get("_lookahead", {}).pop(threading.get_ident(), None)
         if hit is not None and hit[0] is dpb["x_ref"] and hit[1] is dpb["feature_ref"]:
             return hit[2]

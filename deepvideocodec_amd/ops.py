@@ -327,6 +327,18 @@ def dual_prior_pass1(y: Tensor, means: Tensor, scales: Tensor) -> Tensor:
     return out
 
 
+def process_with_mask(y: Tensor, means: Tensor, scales: Tensor, mask: Tensor):
+    """-> (y_quant, y_hat, means_hat, scales_hat) of the reference's process_with_mask (video_model.py:161-167);
+    `mask`: (1, 1, h, w) or (h, w) floats."""
+    n, c, h, w = y.shape
+    _check_vec(mask, h * w, "process_with_mask mask", device=y.device)
+    outs = [torch.empty((n, c, h, w), dtype=torch.float32, device=y.device) for _ in range(4)]
+    check(_lib.load().dvc_process_with_mask(C.byref(_src(y, "y")), C.byref(_src(means, "means")),
+                                            C.byref(_src(scales, "scales")), mask.data_ptr(), *[C.byref(_dst(o)) for o in outs],
+                                            n, h, w, _stream()), "dvc_process_with_mask")
+    return tuple(outs)
+
+
 def dual_prior_pass2(y: Tensor, means: Tensor, scales: Tensor, spatial: Tensor, noise: Optional[Tensor] = None,
                      want=("y_hat", "means_hat", "scales_hat", "likelihood"), scale_table: Optional[Tensor] = None):
     """-> dict with the requested tensors; 'symbols' in `want` also yields 'indexes'

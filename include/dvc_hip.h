@@ -210,6 +210,14 @@ int dvc_eb_dequantize(const int32_t* symbols, const float* medians, const DvcDst
 int dvc_dual_prior_pass1(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales,
                          const DvcDst* yhat1, int32_t batch, int32_t h, int32_t w, void* stream);
 
+/* process_with_mask as the reference states it (video_model.py:161-167 / 333-339), for callers that use that
+ * helper directly (the coding path uses the fused passes above / below): `mask` is one (h, w) plane of floats
+ * shared by every sample and channel; means_hat = means * mask, scales_hat = scales * mask,
+ * y_quant = round((y - means_hat) * mask), y_hat = y_quant + means_hat.  Any destination may have ptr NULL. */
+int dvc_process_with_mask(const DvcSrc* y, const DvcSrc* means, const DvcSrc* scales, const float* mask,
+                          const DvcDst* y_quant, const DvcDst* y_hat, const DvcDst* means_hat,
+                          const DvcDst* scales_hat, int32_t batch, int32_t h, int32_t w, void* stream);
+
 /* Second pass + merge + Gaussian likelihood (video_model.py:192-216,232 and compressai
  * GaussianConditional): `spatial` is the y_spatial_prior output (2C channels:
  * mu0, sigma0, mu1, sigma1).  Outputs (any may have ptr NULL): y_hat, means_hat,

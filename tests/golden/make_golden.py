@@ -141,6 +141,63 @@ def main():
         np.savez_compressed(os.path.join(HERE, "codec_64.npz"), **to_np(codec))
         print("codec_64.npz written")
 
+        # (d) the remaining blocks of the P-frame chain, one by one, from the reference's own modules
+        #     (video_model.py:15-125, 128-150, 294-322, 490-506; layers.py:369-394) and the reference's
+        #     forward_dual_prior / process_with_mask (video_model.py:161-216) in both modes
+        g2 = torch.Generator().manual_seed(4321)
+        rn = lambda *shape, s=0.5: torch.randn(*shape, generator=g2) * s
+        b2 = {}
+        b2["x_ref"], b2["x_cur"] = synthetic_gop(2, 32, 32, seed=21)   # (32 x 32 keeps the fixture small)
+        b2["feature_ref"] = rn(1, 64, 32, 32)
+        b2["mv"] = rn(1, 2, 32, 32, s=2.0)
+        for tag, dpb in (("I", {"x_ref": b2["x_ref"], "feature_ref": None}),
+                         ("P", {"x_ref": b2["x_ref"], "feature_ref": b2["feature_ref"]})):
+            feats = net.multi_scale_feature_extractor(dpb)
+            for i, f in enumerate(feats):
+                b2[f"extractor_{tag}{i}"] = f
+            c1, c2, c3, warp = net.motion_compensation(b2["mv"], dpb)
+            b2[f"mc_{tag}_c1"], b2[f"mc_{tag}_c2"], b2[f"mc_{tag}_c3"], b2[f"mc_{tag}_warp"] = c1, c2, c3, warp
+        ctx1, ctx2, ctx3 = rn(1, 64, 32, 32), rn(1, 64, 16, 16), rn(1, 64, 8, 8)
+        b2["ctx1"], b2["ctx2"], b2["ctx3"] = ctx1, ctx2, ctx3
+        y = net.contextual_encoder(b2["x_cur"], ctx1, ctx2, ctx3)
+        b2["ctx_enc_y"] = y
+        y_hat = torch.round(y)
+        b2["ctx_dec_in"] = y_hat
+        res = net.contextual_decoder(y_hat, ctx2, ctx3)
+        b2["ctx_dec_out"] = res
+        feature, recon = net.recon_generation_net(res, ctx1)
+        b2["recon_feature"], b2["recon_x"] = feature, recon
+        for name, cm, cy in (("motion", net.motion_context_model, 64), ("frame", net.frame_context_model, 96)):
+            yy = rn(1, cy, 4, 4, s=3.0)
+            b2[f"{name}_y"] = yy
+            z = cm.hyper_encoder(yy)
+            b2[f"{name}_hyper_enc"] = z
+            z_hat = torch.round(z)
+            b2[f"{name}_z_hat"] = z_hat
+            params = cm.hyper_decoder(z_hat)
+            b2[f"{name}_hyper_dec"] = params
+            y_ref = rn(1, cy, 4, 4, s=2.0)
+            b2[f"{name}_y_ref"] = y_ref
+            if name == "frame":
+                b2["frame_temporal_in"] = rn(1, 64, 16, 16)
+                temporal = cm.temporal_prior_encoder(b2["frame_temporal_in"])
+                b2["frame_temporal_prior"] = temporal
+                fused = cm.y_prior_fusion(torch.cat((temporal, params, y_ref), dim=1))
+            else:
+                fused = cm.y_prior_fusion(torch.cat((params, y_ref), dim=1))
+            b2[f"{name}_prior_fusion"] = fused
+            means, scales = fused.chunk(2, 1)
+            mask_0, mask_1 = cm.get_mask(4, 4, yy.device)
+            b2[f"{name}_mask0"], b2[f"{name}_mask1"] = mask_0, mask_1
+            for j, t in enumerate(cm.process_with_mask(yy[:, :cy // 2], means[:, :cy // 2], scales[:, :cy // 2], mask_1)):
+                b2[f"{name}_pwm{j}"] = t
+            for j, t in enumerate(cm.forward_dual_prior(yy, means, scales)):
+                b2[f"{name}_fdp{j}"] = t
+            for j, t in enumerate(cm.forward_dual_prior(yy, means, scales, mode="compress")):
+                b2[f"{name}_fdpc{j}"] = t
+        np.savez_compressed(os.path.join(HERE, "blocks2_32.npz"), **to_np(b2))
+        print("blocks2_32.npz written")
+
 
 if __name__ == "__main__":
     main()

@@ -116,3 +116,19 @@ def test_ops_refuse_cpu_tensors():
     from deepvideocodec_amd import ops
     with pytest.raises(_lib.DvcError):
         ops.flow_warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_reference_style_import_binds_this_implementation():
+    """`from models import DMC` -- the statement dmc/test.py:24 and dmc/train.py:55 use -- works unedited with this
+    repository's root on sys.path, and the class it binds has the reference's state-dict keys."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r); from models import DMC; "
+            "net = DMC(); print(json.dumps(sorted(net.state_dict().keys())))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    keys = json.loads(out.stdout.strip().splitlines()[-1])
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        golden = json.load(f)
+    assert keys == sorted(golden.keys())    # (the fixture maps every key of the reference's state dict to its shape)

@@ -49,3 +49,75 @@ def test_context_fusion(gpu_net):
     out = gpu_net.context_fusion_net(T(g["fusion_in0"]), T(g["fusion_in1"]), T(g["fusion_in2"]))
     for i in range(3):
         _close(out[i], T(g[f"fusion_out{i}"]), f"MultiScaleContextFusion output {i}")
+
+
+def test_public_dual_prior_helpers_match_oracle_and_fused_passes(gpu_net, seeded_sd):
+    """process_with_mask / forward_dual_prior on the mirror classes (dmc/models/video_model.py:161-216): bit-equal to
+    the oracle's restatement of those lines for process_with_mask, and forward_dual_prior (both modes) equal to the
+    fused checkerboard passes the coding path runs."""
+    import torch
+    from deepvideocodec_amd import ops
+    from oracle import dmc_oracle as O
+    g = torch.Generator().manual_seed(11)
+    for model, C in ((gpu_net.motion_context_model, 64), (gpu_net.frame_context_model, 96)):
+        h, w = 20, 36
+        y = torch.randn(2, C, h, w, generator=g) * 4
+        means = torch.randn(2, C, h, w, generator=g)
+        scales = torch.rand(2, C, h, w, generator=g) * 3 - 0.3
+        m0, m1 = O.checkerboard_masks(h, w)
+        gm0, gm1 = model.get_mask(h, w, "cuda:0")
+        assert torch.equal(gm0.cpu(), m0) and torch.equal(gm1.cpu(), m1)
+        want = O.process_with_mask(y[:, :C // 2], means[:, :C // 2], scales[:, :C // 2], m1)
+        got = model.process_with_mask(y.cuda()[:, :C // 2], means.cuda()[:, :C // 2], scales.cuda()[:, :C // 2], gm1)
+        for a, b in zip(got, want):
+            assert torch.equal(a.cpu() + 0.0, b + 0.0)
+        yd, md, sd_ = y.cuda(), means.cuda(), scales.cuda()
+        y_hat, means_hat, scales_hat = model.forward_dual_prior(yd, md, sd_)
+        yhat1 = ops.dual_prior_pass1(yd, md, sd_)
+        spatial = model.y_spatial_prior((yhat1, md, sd_))
+        table = model._scale_table()
+        r = ops.dual_prior_pass2(yd, md, sd_, spatial, want=("y_hat", "means_hat", "scales_hat", "symbols"),
+                                 scale_table=table)
+        assert torch.equal(y_hat, r["y_hat"])
+        assert torch.equal(means_hat + 0.0, r["means_hat"] + 0.0) and torch.equal(scales_hat + 0.0, r["scales_hat"] + 0.0)
+        y_hat_c, qw0, qw1, sw0, sw1 = model.forward_dual_prior(yd, md, sd_, mode="compress")
+        assert torch.equal(y_hat_c, y_hat)
+        assert torch.equal(qw0.int(), r["symbols"][0]) and torch.equal(qw1.int(), r["symbols"][1])
+        idx = model.gaussian_conditional.build_indexes(sw0)
+        assert torch.equal(idx.int().reshape(r["indexes"][0].shape), r["indexes"][0])
+
+
+def test_remaining_blocks_match_reference_fixture(gpu_net):
+    """Feature extractor (intra / inter adaptor), motion compensation, contextual encoder / decoder, reconstruction
+    net, hyper encoder / decoder, prior fusion (with the temporal prior) -- block by block against outputs of the
+    reference's own modules (tests/golden/blocks2_32.npz; dmc/models/video_model.py:15-125,128-150,294-322,490-506),
+    and the reference's process_with_mask / forward_dual_prior in both modes against the mirror's methods."""
+    g = {k: T(v) for k, v in load_golden("blocks2_32.npz").items()}
+    net = gpu_net
+    for tag, dpb in (("I", {"x_ref": g["x_ref"], "feature_ref": None}),
+                     ("P", {"x_ref": g["x_ref"], "feature_ref": g["feature_ref"]})):
+        for i, f in enumerate(net.multi_scale_feature_extractor(dpb)):
+            _close(f, g[f"extractor_{tag}{i}"], f"feature extractor ({tag}) level {i}")
+        c1, c2, c3, warp = net.motion_compensation(g["mv"], dpb)
+        for got, name in ((c1, "c1"), (c2, "c2"), (c3, "c3"), (warp, "warp")):
+            _close(got, g[f"mc_{tag}_{name}"], f"motion_compensation ({tag}) {name}")
+    _close(net.contextual_encoder(g["x_cur"], g["ctx1"], g["ctx2"], g["ctx3"]), g["ctx_enc_y"], "ContextualEncoder")
+    _close(net.contextual_decoder(g["ctx_dec_in"], g["ctx2"], g["ctx3"]), g["ctx_dec_out"], "ContextualDecoder")
+    feature, recon = net.recon_generation_net(g["ctx_dec_out"], g["ctx1"])
+    _close(feature, g["recon_feature"], "ReconGeneration feature")
+    _close(recon, g["recon_x"], "ReconGeneration x")
+    for name, cm, cy in (("motion", net.motion_context_model, 64), ("frame", net.frame_context_model, 96)):
+        _close(cm.hyper_encoder(g[f"{name}_y"]), g[f"{name}_hyper_enc"], name + " hyper_encoder")
+        _close(cm.hyper_decoder(g[f"{name}_z_hat"]), g[f"{name}_hyper_dec"], name + " hyper_decoder")
+        means, scales = cm._prior_params(g[f"{name}_z_hat"], g[f"{name}_y_ref"], g.get("frame_temporal_in"))
+        _close(torch.cat((means, scales), 1), g[f"{name}_prior_fusion"], name + " y_prior_fusion")
+        means, scales = g[f"{name}_prior_fusion"].chunk(2, 1)
+        y = g[f"{name}_y"]
+        m0, m1 = cm.get_mask(4, 4, y.device)
+        assert torch.equal(m0, g[f"{name}_mask0"]) and torch.equal(m1, g[f"{name}_mask1"])
+        for j, t in enumerate(cm.process_with_mask(y[:, :cy // 2], means[:, :cy // 2], scales[:, :cy // 2], m1)):
+            assert torch.equal(t + 0.0, g[f"{name}_pwm{j}"] + 0.0), (name, j)
+        for j, t in enumerate(cm.forward_dual_prior(y, means, scales)):
+            _close(t, g[f"{name}_fdp{j}"], f"{name} forward_dual_prior[{j}]")
+        for j, t in enumerate(cm.forward_dual_prior(y, means, scales, mode="compress")):
+            _close(t, g[f"{name}_fdpc{j}"], f"{name} forward_dual_prior(compress)[{j}]")

@@ -5,7 +5,10 @@ decoded-picture buffer for 11 (GOP 12) or 31 (GOP 32, the reference's hard-coded
 
 Asserted on the GOP average: |dPSNR| <= 1e-3 dB and |dbpp| <= 1e-4, bpp from the bytes actually written
 (dmc/test.py:213-217).  The per-frame drift is printed.  The exact fp32 path and the two split-operand modes
-(fp16 and bf16 hi + lo parts on the 16-bit matrix instructions) are held to the same bar against one oracle run."""
+(fp16 and bf16 hi + lo parts on the 16-bit matrix instructions) are held to the same bar against one oracle run.
+The last case is the benchmark's own configuration: 1080 x 1920 (padded to 1088 x 1920), GOP 12, 11 P frames,
+the GOP bench.py codes with seed 0 (about 130 s of oracle time on 16 host threads); per-frame |dPSNR| is held to
+the same 1e-3 dB there as well."""
 import math
 
 import pytest
@@ -34,7 +37,8 @@ def _code_gop(enc_fn, dec_fn, frames, to_dev, clamp):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("gop,size,seed", [(12, 256, 31), (32, 128, 32), (4, (180, 420), 33)])
+@pytest.mark.parametrize("gop,size,seed", [(12, 256, 31), (32, 128, 32), (4, (180, 420), 33), (12, (1080, 1920), 0)],
+                         ids=["gop12-256", "gop32-128", "gop4-180x420", "gop12-1080p"])
 def test_free_running_gop_matches_oracle(gpu_net, seeded_sd, oracle_entropy, gop, size, seed):
     from deepvideocodec_amd import ops
     from deepvideocodec_amd.testing import pad_to_multiple, synthetic_gop
@@ -72,10 +76,12 @@ def test_free_running_gop_matches_oracle(gpu_net, seeded_sd, oracle_entropy, gop
             psnr_g = sum(p for _, p, _ in got) / n
             print(f"GOP {gop} at {h}x{w} [{mode}]: GPU {bpp_g:.5f} bpp {psnr_g:.4f} dB | oracle {bpp_r:.5f} bpp "
                   f"{psnr_r:.4f} dB | first differing stream: {first_diff}")
-            results[mode] = (bpp_g, psnr_g)
+            results[mode] = (bpp_g, psnr_g, max(abs(pg - pr) for (_, pg, _), (_, pr, _) in zip(got, ref)))
     finally:
         gpu_net.set_precision(os.environ.get("DVC_TEST_PRECISION", "fp32"))
     assert 0.02 <= bpp_r <= 1.5, bpp_r
-    for mode, (bpp_g, psnr_g) in results.items():
+    for mode, (bpp_g, psnr_g, worst_frame) in results.items():
         assert abs(psnr_g - psnr_r) <= 1e-3, (mode, psnr_g, psnr_r)
         assert abs(bpp_g - bpp_r) <= 1e-4, (mode, bpp_g, bpp_r)
+        if h * w >= 1088 * 1920:
+            assert worst_frame <= 1e-3, (mode, worst_frame)

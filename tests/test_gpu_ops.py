@@ -589,6 +589,10 @@ def test_conv2d_plane_sums_feed_the_se_gate(cin, cout, H, W, batch, out_slope):
     out, sums = ops.conv2d(x, w, b, out_slope=out_slope, plane_sums=True)
     assert sums is not None and sums.shape[:2] == (batch, cout)
     assert torch.equal(out, plain)
+    want = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)       # an implementation that shares nothing with the kernel
+    want = want if out_slope is None else F.leaky_relu(want, out_slope)
+    close(out, want)
+    close(sums.sum(dim=2), want.double().sum(dim=(2, 3)).float(), rel=2e-6)
     close(sums.sum(dim=2), plain.double().sum(dim=(2, 3)).float().cpu(), rel=2e-6)
     gate = ops.se_gate_from_sums(sums, H, W, fc1, fc2)
     close(gate, ops.se_gate(plain, fc1, fc2).cpu(), rel=1e-6)

@@ -35,6 +35,14 @@ N_FRAMES = 3
 MODES = {"fp32": (1.0, 1.0, True), "fp16x2": (1.0, 1.0, True), "bf16x2": (1.0, 5.0, False), "bf16": (20.0, 200.0, False)}
 
 
+ELEMENTWISE_BAR = {"fp32": 1e-4, "fp16x2": 1e-4, "bf16x2": 1e-3}
+
+
+def rel_err(got, want):
+    """max |got - want| relative to the largest magnitude of the reference tensor."""
+    return float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+
+
 def _near_tie(pre, tol=2e-3):
     frac = pre - torch.floor(pre)
     return (frac - 0.5).abs() <= tol * pre.abs().clamp_min(1.0)
@@ -54,7 +62,9 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
     frames = [pad_to_multiple(f, 64) for f in synthetic_gop(1 + N_FRAMES, 1080, 1920, seed=4)]
     n_pix = 1088 * 1920
     dpb = {"x_ref": frames[0], "feature_ref": None, "y_ref": None, "y_mv_ref": None}
-    report, rate = [], {}
+    report, rate, elementwise = [], {}, []
+    models = {"motion_context_model": gpu_net.motion_context_model, "frame_context_model": gpu_net.frame_context_model}
+    medians = {k: seeded_sd[k + ".entropy_bottleneck.quantiles"][:, 0, 1].reshape(1, -1, 1, 1) for k in models}
     try:
         with torch.no_grad():
             for i in range(1, 1 + N_FRAMES):
@@ -65,9 +75,11 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
                 dpb_g = {k: (None if v is None else v.cuda()) for k, v in dpb.items()}
                 for mode in MODES:
                     gpu_net.set_precision(mode)
+                    for m in models.values():
+                        m.trace = {}
                     x_g, lik_g, ctx_g = gpu_net.forward_inter(frames[i].cuda(), dpb_g)
                     lik_g = {a: {b: t.cpu() for b, t in v.items()} for a, v in lik_g.items()}
-                    flips, origin = 0, False
+                    flips, origin, clean = 0, False, {}
                     for k, key in (("y_mv_ref", "motion_context_model"), ("y_ref", "frame_context_model")):
                         diff = (ctx_g[k].cpu() - ctx_o[k]).abs() > 0.5
                         flips += int(diff.sum())
@@ -75,11 +87,28 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
                         z_diff = (lik_g[label]["z"] - lik_o[label]["z"]).abs() > 1e-3 * lik_o[label]["z"]
                         origin = origin or bool((diff & _near_tie(trace[key]["y_pre"])).any()) or \
                             bool((z_diff & _near_tie(trace[key]["z_pre"])).any())
+                        # this model and everything upstream of it quantised exactly like the oracle
+                        clean[key] = flips == 0 and not bool(z_diff.any()) and all(clean.values())
                     report.append((i, mode, psnr(frames[i], x_g.cpu()) - p_o, bpp(lik_g, n_pix) - b_o, flips,
                                    origin or flips == 0))
+                    # element-wise, independent of the operating point: what the quantisers see, the reconstruction
+                    # and the propagated feature -- wherever every upstream latent rounded the same way (a flipped
+                    # latent legitimately moves the means / the decoded flow around it)
+                    el = {}
+                    for key, m in models.items():
+                        if clean[key]:
+                            y_pre_g = (m.trace["y"] - m.trace["means_hat"]).cpu()
+                            el[key + ".y_pre"] = rel_err(y_pre_g, trace[key]["y_pre"])
+                            el[key + ".z_pre"] = rel_err(m.trace["z"].cpu() - medians[key], trace[key]["z_pre"])
+                    if all(clean.values()):
+                        el["x_rec"] = rel_err(x_g.cpu(), x_o)
+                        el["feature"] = rel_err(ctx_g["feature_ref"].cpu(), ctx_o["feature_ref"])
+                    elementwise.append((i, mode, flips, el))
                 dpb = dict(ctx_o)
     finally:
         gpu_net.set_precision("fp32")
+        for m in models.values():
+            m.trace = None
     print("\n".join(f"frame {i} {m}: oracle {rate[i][0]:.4f} bpp / {rate[i][1]:.3f} dB; dPSNR {dp:+.2e} dB, dbpp {db:+.2e}, "
                     f"{fl} of {N_LATENTS} latents differ" for i, m, dp, db, fl, _ in report))
     for i, (b_o, _) in rate.items():
@@ -93,3 +122,15 @@ def test_first_p_frames_1080p_match_oracle(gpu_net, seeded_sd, oracle_entropy):
     for mode, (_, kf, _) in MODES.items():
         total = sum(r[4] for r in report if r[1] == mode)
         assert total <= kf * FLIP_FRACTION * N_LATENTS * N_FRAMES, (mode, total)
+    print("\n".join(f"frame {i} {m} ({fl} flips): " + ", ".join(f"{k} {v:.1e}" for k, v in el.items())
+                    for i, m, fl, el in elementwise))
+    # element-wise bars (max |gpu - oracle| / max |oracle|): 1e-4 for the exact fp32 path and the 22-bit fp16 split,
+    # 1e-3 for the 16-bit bf16 split; the single-part bf16 mode is outside them (reported above, not asserted)
+    for i, mode, flips, el in elementwise:
+        bar = ELEMENTWISE_BAR.get(mode)
+        if bar is None:
+            continue
+        for name, err in el.items():
+            assert err <= bar, f"frame {i} {mode}: {name} differs from the oracle by {err:.2e} of its range (bar {bar:.0e})"
+    assert any(m == "fp32" and "x_rec" in el for _, m, _, el in elementwise), \
+        "no frame without flipped latents: the reconstruction was never compared element-wise"

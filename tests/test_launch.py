@@ -30,7 +30,7 @@ def _result(stdout):
 def test_plain_start_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher: two ranks appear, n_gpus == 2, every GOP is coded once."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "1", "--steps", "2",
-                        "--warmup", "1"], capture_output=True, text=True, env=_clean_env(), timeout=280)
+                        "--warmup", "1", "--gops-in-flight", "3"], capture_output=True, text=True, env=_clean_env(), timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     out = _result(r.stdout)
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["ranks"] == [0, 1]
@@ -62,3 +62,21 @@ def test_resolve_world_single_process(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8")
     with pytest.raises(launch.WorldError):          # rank variables missing
         launch.resolve_world(8, "x.py", [])
+
+
+def test_host_budget_sizes_threads_per_rank(monkeypatch):
+    """Cores a rank may count on = CPUs allowed / ranks of the node (capped by an OMP_NUM_THREADS >= 2), and the
+    GOP threads / coder pool derived from it: eight ranks on a small host shrink instead of oversubscribing it."""
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)), raising=False)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    b = launch.host_budget()
+    assert b == {"cpus_allowed": 32, "local_world": 8, "cores_per_rank": 4}
+    assert launch.default_gops_in_flight(4) == 2 and launch.coder_pool_workers(4) == 2
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    monkeypatch.setenv("OMP_NUM_THREADS", "16")
+    assert launch.host_budget()["cores_per_rank"] == 16
+    assert launch.default_gops_in_flight(16) == 3 and launch.coder_pool_workers(16) == 6
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")          # torch.distributed.run's default export: ignored
+    assert launch.host_budget()["cores_per_rank"] == 32
+    assert launch.default_gops_in_flight(1) == 1 and launch.coder_pool_workers(1) == 2

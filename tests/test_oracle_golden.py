@@ -96,3 +96,44 @@ def test_decode_reproduces_forward(seeded_sd, oracle_entropy):
         enc = O.encode_inter(sd, ent, frames[1], dpb)
         rec, _ = O.decode_inter(sd, ent, enc["strings"], enc["shape"], dpb)
     assert torch.allclose(rec, fwd["x_hat"][0], atol=1e-5)
+
+
+def test_remaining_blocks_match_reference(seeded_sd):
+    """Feature extractor (intra and inter adaptor), motion compensation, contextual encoder / decoder,
+    reconstruction net, hyper encoder / decoder, prior fusion, temporal prior and the reference's own
+    process_with_mask / forward_dual_prior (both modes), block by block (tests/golden/blocks2_32.npz)."""
+    g = {k: T(v) for k, v in load_golden("blocks2_32.npz").items()}
+    sd = seeded_sd
+    ok = lambda a, b: torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    with torch.no_grad():
+        for tag, dpb in (("I", {"x_ref": g["x_ref"], "feature_ref": None}),
+                         ("P", {"x_ref": g["x_ref"], "feature_ref": g["feature_ref"]})):
+            feat = O.conv(sd, "feature_adaptor_I", dpb["x_ref"]) if tag == "I" else O.conv(sd, "feature_adaptor_P", dpb["feature_ref"])
+            for i, f in enumerate(O.feature_extractor(sd, feat)):
+                assert ok(f, g[f"extractor_{tag}{i}"]), (tag, i)
+            c1, c2, c3, warp = O.motion_compensation(sd, g["mv"], dpb)
+            assert ok(c1, g[f"mc_{tag}_c1"]) and ok(c2, g[f"mc_{tag}_c2"]) and ok(c3, g[f"mc_{tag}_c3"])
+            assert ok(warp, g[f"mc_{tag}_warp"])
+        assert ok(O.contextual_encoder(sd, g["x_cur"], g["ctx1"], g["ctx2"], g["ctx3"]), g["ctx_enc_y"])
+        assert ok(O.contextual_decoder(sd, g["ctx_dec_in"], g["ctx2"], g["ctx3"]), g["ctx_dec_out"])
+        # the reference calls recon_generation_net(x_rec_feature, context1): video_model.py:575
+        feature, recon = O.recon_generation(sd, g["ctx_dec_out"], g["ctx1"])
+        assert ok(feature, g["recon_feature"]) and ok(recon, g["recon_x"])
+        for name, cy in (("motion", 64), ("frame", 96)):
+            key = name + "_context_model"
+            assert ok(O.hyper_encoder(sd, key + ".hyper_encoder", g[f"{name}_y"]), g[f"{name}_hyper_enc"])
+            assert ok(O.hyper_decoder(sd, key + ".hyper_decoder", g[f"{name}_z_hat"]), g[f"{name}_hyper_dec"])
+            means, scales = O.context_model_params(sd, key, g[f"{name}_y"], g[f"{name}_y_ref"], g[f"{name}_z_hat"],
+                                                   g.get("frame_temporal_in"))
+            fused = g[f"{name}_prior_fusion"]
+            assert ok(torch.cat((means, scales), 1), fused)
+            means, scales = fused.chunk(2, 1)
+            m0, m1 = O.checkerboard_masks(4, 4)
+            assert torch.equal(m0, g[f"{name}_mask0"]) and torch.equal(m1, g[f"{name}_mask1"])
+            y = g[f"{name}_y"]
+            for j, t in enumerate(O.process_with_mask(y[:, :cy // 2], means[:, :cy // 2], scales[:, :cy // 2], m1)):
+                assert torch.equal(t + 0.0, g[f"{name}_pwm{j}"] + 0.0), (name, j)
+            for j, t in enumerate(O.dual_prior(sd, key, y, means, scales)):
+                assert ok(t, g[f"{name}_fdp{j}"]), (name, j)
+            for j, t in enumerate(O.dual_prior(sd, key, y, means, scales, compress=True)):
+                assert ok(t, g[f"{name}_fdpc{j}"]), (name, j)

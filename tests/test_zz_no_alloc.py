@@ -50,3 +50,49 @@ def test_static_scratch_gate_rejects_oversize():
     rc = lib.dvc_se_gate_static(C.byref(ops._src(x)), n, 2, 2, fc1.data_ptr(), fc2.data_ptr(), 16, gate.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)
     assert rc == -1 and "exceeds the built-in scratch" in _lib.last_error()
+
+
+def test_static_scratch_gate_allocates_nothing_and_captures():
+    """What the entry point exists for: a (warm) call leaves the device's free memory and torch's allocation counter
+    where they were, and it can be recorded into a HIP graph (an allocation inside capture would fail it) whose
+    replay gives the same bits.  The first call on a device looks the scratch address up and must be made outside
+    capture; this test makes it first."""
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(8)
+    n, c, h, w = 1, 64, 68, 120
+    x = torch.randn(n, c, h, w, generator=g).to(dev)
+    fc1 = (torch.randn(c // 16, c, generator=g) * 0.3).to(dev)
+    fc2 = (torch.randn(c, c // 16, generator=g) * 0.3).to(dev)
+    want = ops.se_gate(x, fc1, fc2)
+    got = torch.zeros(n * c, device=dev)
+    src = ops._src(x)
+
+    def call(stream):
+        rc = lib.dvc_se_gate_static(C.byref(src), n, h, w, fc1.data_ptr(), fc2.data_ptr(), fc1.size(0), got.data_ptr(), stream)
+        assert rc == 0, _lib.last_error()
+
+    call(torch.cuda.current_stream().cuda_stream)          # warm: per-device symbol lookup happens here
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    count0 = torch.cuda.memory_stats(dev)["allocation.all.allocated"]
+    got.zero_()
+    call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, (free0, free1)
+    assert torch.cuda.memory_stats(dev)["allocation.all.allocated"] == count0
+    assert torch.equal(got, want)
+    # under stream capture
+    got.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            call(side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    assert float(got.abs().max()) == 0.0                   # capture records, it does not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
