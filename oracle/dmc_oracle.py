@@ -356,7 +356,8 @@ def context_model_forward(sd, ent: EntropyState, key, y, y_ref, context3=None, t
     y_hat, means_hat, scales_hat = dual_prior(sd, key, y, means, scales)
     _, y_lik = gc(y, scales_hat, means_hat)
     if trace is not None:
-        trace[key] = {"z_pre": z - med, "z_hat": z_hat, "y_pre": y - means_hat, "y_hat": y_hat}
+        trace[key] = {"z_pre": z - med, "z_hat": z_hat, "y_pre": y - means_hat, "y_hat": y_hat, "y": y,
+                      "means": means, "scales": scales}
     return y_hat, {"y": y_lik, "z": z_lik}
 
 
