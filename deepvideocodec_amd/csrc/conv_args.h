@@ -53,6 +53,11 @@ int conv_mfma_run_p2_k1(const ConvArgs& a, int ksize, int stride, int batch, hip
 int conv_mfma_run_p3_k3(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
 int conv_mfma_run_p3_k1(const ConvArgs& a, int ksize, int stride, int batch, hipStream_t st);
 
+// conv_mfma_k7_p*.hip: 7x7 stride 1 in the reduced-operand modes (precision 1..3)
+int conv_mfma_run_k7_reduced(const ConvArgs& a, int precision, int batch, hipStream_t st);
+int conv_mfma_run_k7_p2(const ConvArgs& a, int batch, hipStream_t st);
+int conv_mfma_run_k7_p3(const ConvArgs& a, int batch, hipStream_t st);
+
 // conv_thin.hip: direct convolution for layers with at most 4 output channels
 bool thin_conv_applies(const ConvArgs& a, int ksize, int stride, int batch);
 int launch_thin_conv(const ConvArgs& a, int ksize, int batch, hipStream_t st);

@@ -48,6 +48,38 @@ __global__ __launch_bounds__(256) void pack_weight_half_kernel(const float* w, t
   }
 }
 
+// Reduced-operand image of a 3x3 / 7x7 stride-1 layer: [cout block][chunk of 16 channels][tap row ky][step slab], a
+// step slab = [part][kx][octet][co][8 channels] in 16-bit elements, zero filled past Cin / Cout / the slab's payload.
+template <bool F16>
+__global__ __launch_bounds__(256) void pack_weight_step_kernel(const float* w, typename Half16<F16>::T* packed, int cout, int cin,
+                                                               int ks, int cb, int parts, int step_elems, int nchunks,
+                                                               long long total) {
+  const int payload = parts * ks * 2 * cb * 8;   // 16-bit elements of a slab that carry weights
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i % step_elems);
+    long long t = i / step_elems;
+    const int ky = (int)(t % ks);
+    t /= ks;
+    const int chunk = (int)(t % nchunks), blk = (int)(t / nchunks);
+    float v = 0.f;
+    int part = 0;
+    if (e < payload) {
+      const int e8 = e & 7;
+      int u = e >> 3;
+      const int col = u % cb;
+      u /= cb;
+      const int o = u & 1;
+      u >>= 1;
+      const int kx = u % ks;
+      part = u / ks;
+      const int ci = chunk * BF_CK + o * 8 + e8, co = blk * cb + col;
+      if (ci < cin && co < cout) v = w[((long long)co * cin + ci) * ks * ks + ky * ks + kx];
+    }
+    const auto hi = to_half16<F16>(v);
+    packed[i] = part == 0 ? hi : to_half16<F16>(v - (float)hi);
+  }
+}
+
 // OIHW -> [cout block][chunk][row = (ci - c0) * taps + tap][co - cb0], zero filled past Cin / Cout.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* packed, int cout, int cin, int ks,
                                                           int ck, int cb, int slab, int nchunks, long long total) {
@@ -127,22 +159,36 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
 extern "C" int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
                                                            int32_t precision) {
   if (check_geometry(cout, cin, ksize, stride, "dvc_conv2d_reduced_packed_weight_floats")) return DVC_EINVAL;
-  if (ksize == 7 || precision < DVC_PRECISION_BF16 || precision > DVC_PRECISION_FP16X2) {
-    dvc::set_error("dvc_conv2d_reduced_packed_weight_floats: precision 1..3, ksize 1 or 3");
+  if ((ksize == 7 && stride != 1) || precision < DVC_PRECISION_BF16 || precision > DVC_PRECISION_FP16X2) {
+    dvc::set_error("dvc_conv2d_reduced_packed_weight_floats: precision 1..3");
     return DVC_EINVAL;
   }
   const int cb = cout_block_of(cout), parts = precision == DVC_PRECISION_BF16 ? 1 : 2;
-  return (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK) * parts * slab_floats_bf16(ksize, cb);
+  const int64_t slabs = (int64_t)((cout + cb - 1) / cb) * ((cin + BF_CK - 1) / BF_CK);
+  if (reduced_stepped(ksize, stride)) return slabs * ksize * step_slab_floats(ksize, cb, parts);
+  return slabs * parts * slab_floats_bf16(ksize, cb);
 }
 
 extern "C" int dvc_conv2d_reduced_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize,
                                               int32_t stride, int32_t precision, float* packed, void* stream) {
   if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_reduced_pack_weight")) return rc;
-  DVC_REQUIRE(ksize != 7 && precision >= DVC_PRECISION_BF16 && precision <= DVC_PRECISION_FP16X2,
-              "dvc_conv2d_reduced_pack_weight: precision 1..3, ksize 1 or 3");
+  DVC_REQUIRE(precision >= DVC_PRECISION_BF16 && precision <= DVC_PRECISION_FP16X2,
+              "dvc_conv2d_reduced_pack_weight: precision 1..3");
   DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_reduced_pack_weight: null pointer");
   DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_reduced_pack_weight: packed buffer must be 16-byte aligned");
   const int cb = cout_block_of(cout), parts = precision == DVC_PRECISION_BF16 ? 1 : 2;
+  if (reduced_stepped(ksize, stride)) {
+    const int step_elems = 2 * step_slab_floats(ksize, cb, parts), nch = (cin + BF_CK - 1) / BF_CK;
+    const long long tot = (long long)((cout + cb - 1) / cb) * nch * ksize * step_elems;
+    const dim3 g(dvc::stream_grid(tot, 256));
+    if (precision == DVC_PRECISION_FP16X2)
+      hipLaunchKernelGGL(pack_weight_step_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, weight,
+                         reinterpret_cast<_Float16*>(packed), cout, cin, ksize, cb, parts, step_elems, nch, tot);
+    else
+      hipLaunchKernelGGL(pack_weight_step_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, weight,
+                         reinterpret_cast<__bf16*>(packed), cout, cin, ksize, cb, parts, step_elems, nch, tot);
+    return dvc::check_launch("pack_weight_step_kernel");
+  }
   const int part_elems = 2 * slab_floats_bf16(ksize, cb), nchunks = (cin + BF_CK - 1) / BF_CK;
   const long long total = (long long)((cout + cb - 1) / cb) * nchunks * part_elems * parts;
   const dim3 grid(dvc::stream_grid(total, 256));
@@ -259,8 +305,9 @@ extern "C" int dvc_conv2d(const DvcConv2d* p, void* stream) {
     a.vec4 = al(a.out, a.obs, a.ocs) && (!a.res || al(a.res, a.rbs, a.rcs)) && (!a.res2 || al(a.res2, a.r2bs, a.r2cs));
   }
   if (p->precision != DVC_PRECISION_FP32) {
-    DVC_REQUIRE(p->ksize != 7 && p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,
-                "dvc_conv2d: precision %d unknown, or a reduced-operand mode with ksize 7", p->precision);
+    DVC_REQUIRE(p->precision >= DVC_PRECISION_BF16 && p->precision <= DVC_PRECISION_FP16X2,
+                "dvc_conv2d: precision %d unknown", p->precision);
+    if (p->ksize == 7) return dvc::conv_mfma_run_k7_reduced(a, p->precision, p->batch, st);
     if (p->precision == DVC_PRECISION_BF16) return dvc::conv_mfma_run_p1(a, p->ksize, p->stride, p->batch, st);
     if (p->precision == DVC_PRECISION_BF16X2)
       return p->ksize == 3 ? dvc::conv_mfma_run_p2_k3(a, 3, p->stride, p->batch, st)

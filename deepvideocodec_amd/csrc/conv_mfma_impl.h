@@ -74,9 +74,10 @@ constexpr int slab_floats(int ks, int s, int cb) { return dvc::conv_slab_floats(
 // given here in 4-byte units like the fp32 slabs (padded to whole 1 KiB pieces).
 constexpr int BF_CK = 16;
 constexpr int slab_floats_bf16(int ks, int cb) { return (ks * ks * 2 * cb * 4 + 255) / 256 * 256; }
-
-template <int MT, int NT>
-constexpr int min_waves_per_simd() { return 2; }
+// 3x3 / 7x7 stride 1 in the reduced-operand modes: one slab per (chunk, tap row), [part][kx][octet][co][8 x 16 bit],
+// padded to whole 4 KiB (Geo::STEPPED / Geo::WSTEP)
+constexpr bool reduced_stepped(int ks, int s) { return ks != 1 && s == 1; }
+constexpr int step_slab_floats(int ks, int cb, int parts) { return (parts * ks * 2 * cb * 4 + 1023) / 1024 * 1024; }
 
 // HALF: a 32-channel workgroup (MT = 1) working on one half of a 64-channel packed weight block,
 // used to double the number of workgroups of small launches whose weights are packed 64 wide.
@@ -96,10 +97,19 @@ template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY =
 struct Geo {
   static_assert(!HALF || MT == 1, "half blocks are 32 channels");
   static_assert(DY == 1 || (DY == 2 && KS == 7 && S == 1 && MT == 1 && !HALF && BF == 0), "row pairs: 7x7 stride 1 fp32");
-  static_assert(!BF || KS != 7, "the reduced-operand modes cover the 1x1 and 3x3 layers");
   static constexpr int PARTS = BF >= 2 ? 2 : 1;
   static constexpr bool F16 = BF == 3;
-  static constexpr int NBUF = PARTS == 2 ? 1 : 2;   // LDS buffers per operand
+  // Reduced-operand 3x3 / 7x7 stride-1 kernels walk K in STEPS of (16-channel chunk, one tap row): the weights of a
+  // step are one small slab that is DMA'd into a ring of NW slots one or two steps before it is read, so no wave ever
+  // waits for a weight slab it has just asked for, and the 49-tap weights of a 7x7 chunk (200 KiB in two parts)
+  // never have to be resident at once.  The converted input tile of a chunk stays for its KS steps; 3x3 keeps two of
+  // them, so the next chunk is converted and written while the current one multiplies.
+  static constexpr bool STEPPED = BF != 0 && KS != 1 && S == 1;
+#ifndef DVC_STEP_RING
+#define DVC_STEP_RING 2
+#endif
+  static constexpr int NW = KS == 3 ? DVC_STEP_RING : 2;
+  static constexpr int NBUF = STEPPED ? (KS == 3 && DVC_STEP_RING == 3 ? 2 : 1) : (PARTS == 2 ? 1 : 2);   // LDS buffers of the input tile
   static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
@@ -117,7 +127,14 @@ struct Geo {
   static constexpr int IN_BUF = ((BF ? 8 * PARTS : CK) * CHS + 3) / 4 * 4;   // keep 16-byte alignment of what follows
   static constexpr int IN_PT = (CHS + 255) / 256;         // input elements per thread per channel
   static constexpr int GS = (KS == 1) ? S : 1;            // global step between staged pixels
-  static constexpr int STAGE_BYTES = NBUF * (IN_BUF + SLAB) * 4;
+  // step slab [part][kx][octet][co][8 x 16 bit] in 4-byte units, padded to whole 4 KiB (each of the four waves
+  // moves the same number of 1 KiB pieces: the counted waits below rely on it)
+  static constexpr int WSTEP = (PARTS * KS * 2 * CBP * 4 + 1023) / 1024 * 1024;
+  static constexpr int W_UNITS = STEPPED ? NW * WSTEP : NBUF * SLAB;   // LDS of the weights, 4-byte units
+  static constexpr int STAGE_BYTES = (W_UNITS + NBUF * IN_BUF) * 4;
+  // workgroups per CU the LDS allows (the register budget follows it)
+  // (three per CU only where a wave's accumulators leave room in a 168-register budget: 64 of them at most)
+  static constexpr int MIN_WAVES = !STEPPED ? 2 : STAGE_BYTES > 80 * 1024 ? 1 : (STAGE_BYTES + 320 > 53 * 1024 || MT * NT > 4) ? 2 : 3;
   // four wave-private 32 x 36 transposition tiles + the four waves' per-channel sums (plane-sum output)
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + 4 * 64 * 4;
   static constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
@@ -158,8 +175,17 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #define DVC_CSTAMP(cond, slot)
 #endif
 
+// s_barrier that the compiler may not move LDS accesses across (the bare builtin is not a memory operation for the
+// optimiser), without the wait for every outstanding vector-memory request that __syncthreads()'s fences add: the
+// stepped K loop keeps weight-slab DMAs in flight across barriers and places its own counted waits.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
-__global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES)) void conv_mfma_f32_kernel(const ConvArgs a) {
   using G = Geo<KS, S, MT, NT, HALF, BF, DY>;
   constexpr int CBP = G::CBP;
   constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW, SLY = G::SLY;
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NBUF = G::NBUF, PARTS = G::PARTS;
   float* const w_s = lds;                   // [NBUF][SLAB]   (first: 1 KiB-aligned pieces for the LDS DMA)
-  float* const in_s = lds + NBUF * SLAB;    // [NBUF][IN_BUF]
+  float* const in_s = lds + G::W_UNITS;     // [NBUF][IN_BUF]
   float* const bias_s = lds + G::MAIN_BYTES / 4;   // [CB] bias of this workgroup's channels (0 past Cout / without bias)
 
   const int tid = threadIdx.x;
@@ -219,7 +245,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
   }
   const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
-  const float* wslabs = a.wpacked + (long long)wblock * nchunks * SLAB;
+  const float* wslabs = a.wpacked + (long long)wblock * nchunks * (G::STEPPED ? KS * G::WSTEP : SLAB);
 
   float rin[CK][IN_PT];
 
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   // lgkmcnt(0) before every MFMA group, which exposes the LDS latency of the operand reads just issued
   // for the next tap (10 % of the K loop for a wave alone on its SIMD).
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)SLAB), 0x00020000);
+      const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)(G::STEPPED ? KS * G::WSTEP : SLAB)), 0x00020000);
   auto dma_weights = [&](int chunk, int buf) __attribute__((always_inline)) {
     float* dst = w_s + buf * SLAB;
     const unsigned soff = 4u * (unsigned)chunk * (unsigned)SLAB;
@@ -414,6 +440,100 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
   const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
   const int b_lane8 = half * CHS + (wave * NT * SL) * IW + l32 * SL;
 
+  if constexpr (G::STEPPED) {
+    // ---- K loop in steps of (chunk, tap row); see Geo::STEPPED.  Per step: [last row of a chunk: convert the next
+    // chunk's input (requested during row 0) into the other input buffer] -> request the slab NW-1 steps ahead ->
+    // [row 0: request the next chunk's input] -> the row's MFMAs -> wait until the NEXT step's slab has landed (all
+    // but this step's own requests: the counter retires in order) -> barrier.  Hazards: a ring slot is overwritten
+    // NW-1 steps after its last read and an input buffer one chunk after its, each with a barrier in between.
+    constexpr int R = KS, NW = G::NW, WSTEP = G::WSTEP, P = WSTEP / 1024, L = CK * IN_PT;
+    static_assert(NW != 3 || P + L <= 63, "counted vmcnt exceeds the field");
+    using V8 = typename Half16<G::F16>::V8;
+    const int n_steps = nchunks * R;
+    auto dma_step = [&](int step) __attribute__((always_inline)) {
+      const int slot = step % NW;
+      float* dst = w_s + slot * WSTEP;
+      const unsigned soff = 4u * (unsigned)step * (unsigned)WSTEP;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int piece = wave + 4 * p;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                 16u * (unsigned)lane, soff + 1024u * (unsigned)piece, 0, 0);
+      }
+    };
+    // s_waitcnt immediates: vmcnt(n) lgkmcnt(0) (vmcnt is split over bits 3:0 and 15:14, expcnt left at 7)
+    constexpr int kVm0Lgkm0 = 0x0070;
+    constexpr int kVmP = (P & 0xF) | ((P >> 4) << 14) | 0x0070, kVmL = (L & 0xF) | ((L >> 4) << 14) | 0x0070;
+    constexpr int kVmPL = ((P + L) & 0xF) | (((P + L) >> 4) << 14) | 0x0070;
+    dma_step(0);
+    if (NW == 3 && n_steps > 1) dma_step(1);
+    prefetch_input(0);
+    commit_input(0);
+    __builtin_amdgcn_s_waitcnt(kVm0Lgkm0);
+    lds_barrier();
+    DVC_STAMP(1);
+    constexpr int APART = KS * 2 * CBP, BPART = 2 * CHS;   // second operand part, in 16-byte units
+    for (int c = 0; c < nchunks; ++c) {
+      const int cur = NBUF == 2 ? (c & 1) : 0, nxt = NBUF == 2 ? (cur ^ 1) : 0;
+      const bool more = c + 1 < nchunks;
+      const V8* const bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
+      static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const int step = c * R + r;
+        if (NBUF == 2 && r == R - 1 && more) commit_input(nxt);
+        const bool dma_now = step + NW - 1 < n_steps;
+        if (dma_now) dma_step(step + NW - 1);
+        const bool loads_now = r == 0 && more;
+        if (loads_now) prefetch_input((c + 1) * CK);
+        const V8* const abase = reinterpret_cast<const V8*>(w_s + (step % NW) * WSTEP) + a_lane8;
+        if constexpr (r < 3) DVC_CSTAMP(c == 1, 8 + 2 * r);    // (diagnostic build: second chunk, before / after the row's MFMAs)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          V8 ah[MT], al[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = abase[kx * 2 * CBP + mt * 32];
+            if constexpr (PARTS == 2) al[mt] = abase[APART + kx * 2 * CBP + mt * 32];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const V8 bh = bbase[(nt + r) * IW + kx];
+            if constexpr (PARTS == 2) {
+              const V8 bl = bbase[BPART + (nt + r) * IW + kx];
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {   // the small cross terms first, then the leading one
+                acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
+                acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
+                acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
+              }
+            } else {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
+            }
+          }
+        }
+        if constexpr (r < 3) DVC_CSTAMP(c == 1, 9 + 2 * r);
+        if (NBUF == 1 && r == R - 1 && more) {   // one input buffer: everyone is done with it, then it is rewritten
+          __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0) */
+          lds_barrier();
+          commit_input(0);
+        }
+        // the next step's slab: requested one step ago (ring of three: everything this step asked for may stay in
+        // flight) or at the top of this step (ring of two)
+        if (NW == 3) {
+          if (dma_now && loads_now) __builtin_amdgcn_s_waitcnt(kVmPL);
+          else if (dma_now) __builtin_amdgcn_s_waitcnt(kVmP);
+          else if (loads_now) __builtin_amdgcn_s_waitcnt(kVmL);
+          else __builtin_amdgcn_s_waitcnt(kVm0Lgkm0);
+        } else {
+          __builtin_amdgcn_s_waitcnt(kVm0Lgkm0);
+        }
+        if constexpr (r == 2) DVC_CSTAMP(c == 1, 14);
+        lds_barrier();
+        if constexpr (r == 2) DVC_CSTAMP(c == 1, 15);
+      });
+    }
+  } else {
   // ---- prologue: chunk 0 into buffer 0
   dma_weights(0, 0);
   prefetch_input(0);
@@ -582,6 +702,7 @@ __global__ __launch_bounds__(256, (min_waves_per_simd<MT, NT>())) void conv_mfma
     DVC_CSTAMP(k == 2, 12);
     __syncthreads();
   }
+  }   // (ordinary K loop)
 
   DVC_STAMP(2);
 #ifdef DVC_EXP_NO_EPILOGUE   // experiment: how long the launch takes with no epilogue at all (wrong results)
@@ -1018,29 +1139,6 @@ inline int pick_nt(const ConvArgs& a, int batch, int mt, int max_nt) {
   return 1;
 }
 
-// 7x7 stride 1 with exactly 16 output channels (the fourth layer of every SpyNet level: half the MFMA rows would
-// idle): the row-pair form, when the launch is one it covers -- whole tiles, 16-byte rows, plain epilogue -- with
-// the tallest tile that divides the height and still yields two workgroups per CU.  `rowpair_image`: where the
-// packed row-pair image starts (behind the ordinary one).  Returns -1 when the ordinary form has to run.
-inline int launch_rowpair(const ConvArgs& a, int batch, hipStream_t st) {
-  if (!dvc::conv_has_rowpair_image(a.cout, 7, 1) || !a.vec4 || a.res != nullptr || a.ps || a.wo % 32 != 0 ||
-      a.out_slope < 0.f || a.out_slope > 1.f)
-    return -1;
-  const int nchunks = (a.cin + chunk_of(7, 1) - 1) / chunk_of(7, 1);
-  ConvArgs b = a;
-  b.wpacked = a.wpacked + (long long)nchunks * slab_floats(7, 1, 32);
-  const long long tx = a.wo / 32;
-  for (int nt = 4; nt >= 1; nt >>= 1) {
-    if (a.ho % (8 * nt) != 0) continue;
-    const long long blocks = (long long)(a.ho / (8 * nt)) * tx * batch;
-    if (blocks < 480 && nt > 1) continue;
-    if (nt == 4) return launch<7, 1, 1, 4, false, 0, 2>(b, batch, st);
-    if (nt == 2) return launch<7, 1, 1, 2, false, 0, 2>(b, batch, st);
-    return launch<7, 1, 1, 1, false, 0, 2>(b, batch, st);
-  }
-  return -1;
-}
-
 // Partial sums per output plane that a 3x3 stride-1 fp32 launch can emit with its stores (ConvArgs::plane_sums):
 // one per workgroup tile, when the launch is made of whole tiles of the variant dispatch_tile<3, 1, 0> picks, has
 // 16-byte rows, no residual and no PixelShuffle.  0: not available for this launch.
@@ -1073,7 +1171,9 @@ int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
     if (nt == 2) return launch<KS, S, 2, 2, false, BF>(a, batch, st);
     // still fewer than two workgroups per CU with the smallest tile: split the 64-channel blocks
     const long long blocks = (long long)((a.ho + 3) / 4) * ((a.wo + 31) / 32) * ((a.cout + 63) / 64) * batch;
-    if (blocks < 384 && a.plane_sums == nullptr) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
+    if constexpr (!(KS == 7 && BF != 0)) {
+      if (blocks < 384 && a.plane_sums == nullptr) return launch<KS, S, 1, 1, true, BF>(a, batch, st);
+    }
     return launch<KS, S, 2, 1, false, BF>(a, batch, st);
   }
   if (nt == 4) { if constexpr (!(S == 2 && KS != 1)) return launch<KS, S, 1, 4, false, BF>(a, batch, st); }

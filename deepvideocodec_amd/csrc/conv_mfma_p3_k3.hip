@@ -9,3 +9,10 @@ int conv_mfma_run_p3_k3(const ConvArgs& a, int ksize, int stride, int batch, hip
 }
 
 }  // namespace dvc
+
+#ifdef DVC_CONV_STAMPS
+// diagnostic build (make stamps_p3): point this unit's phase stamps at a caller buffer of 16 x workgroups 64-bit words
+extern "C" int dvc_debug_conv_stamps(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -35,12 +35,12 @@ class Conv2d(nn.Module):
         nn.init.constant_(self.bias, 0.01)
 
         self._packed = {}         # compute mode -> (key, kernel-layout image of `weight`)
-        # inference-only option: 16-bit operand arithmetic, fp32 accumulation (1x1 / 3x3 kernels; the
-        # 7x7 motion-estimation layers always stay exact fp32).  See DMC.set_precision().
+        # inference-only option: 16-bit operand arithmetic, fp32 accumulation.  See DMC.set_precision().
         self.precision = 0      # ops.PRECISIONS: 0 exact fp32, 1 bf16, 2 bf16 hi + lo split, 3 fp16 hi + lo split
 
     def _precision(self) -> int:
-        return int(self.precision) if self.kernel_size != 7 else 0
+        # layers with a handful of output channels (the flow and RGB heads) run on the vector ALUs in exact fp32
+        return int(self.precision) if self.out_channels > 4 else 0
 
     def packed_weight(self, precision: int = 0) -> Tensor:
         """The slab-layout copy of the weight the kernel reads (one per compute mode), rebuilt when

@@ -654,8 +654,8 @@ class DMC(nn.Module):
 
     def set_precision(self, precision: str = "fp32"):
         """"fp32" (default): exact fp32 convolutions, the parity path.  The other modes change how the
-        1x1 / 3x3 convolutions form their products (fp32 accumulation and fp32 tensors throughout; the
-        7x7 motion-estimation layers stay fp32; encoder and decoder must use the same setting):
+        convolutions form their products (fp32 accumulation and fp32 tensors throughout; layers with at most four
+        output channels stay exact fp32; encoder and decoder must use the same setting):
         "bf16": operands rounded to bf16 (3-4x faster convolutions, visibly different results);
         "bf16x2": operands split into bf16 hi + lo parts (16 significant bits), three 16-bit matrix
         products per term; "fp16x2": the same with fp16 parts (22 significant bits; operands must stay

@@ -87,7 +87,7 @@ PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x2": 2, "fp16x2": 3}
 def pack_conv_weight(weight: Tensor, stride: int = 1, precision: int = 0) -> Tensor:
     """OIHW weight -> the slab layout dvc_conv2d reads (re-pack whenever the weight changes).
     `precision` (PRECISIONS): 0 exact fp32; 1 bf16-rounded operands; 2 / 3 operands split into bf16 / fp16
-    hi + lo parts (1x1 / 3x3 only)."""
+    hi + lo parts (7x7: stride 1 only)."""
     if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32 and weight.dim() == 4):
         raise ValueError("pack_conv_weight: weight must be a contiguous fp32 OIHW GPU tensor")
     cout, cin, k, k2 = weight.shape

@@ -94,7 +94,7 @@ typedef struct DvcConv2d {
   int64_t res2_batch_stride, res2_chan_stride;
   int32_t precision;               /* DVC_PRECISION_*: how the products are formed (fp32 accumulation and fp32
                                       tensors in every mode); weight_packed must have been packed for the
-                                      same mode.  Modes other than FP32 cover ksize 1 and 3 */
+                                      same mode.  Modes other than FP32: ksize 7 with stride 1 only */
   int32_t _pad;
   float* plane_sums;               /* optional [batch][Cout][dvc_conv2d_plane_sum_slots()]: with its stores, every
                                       workgroup also writes the sum of the values it stored per output channel --
@@ -122,9 +122,12 @@ int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
 
-/* The same for the reduced-operand modes (precision = DVC_PRECISION_BF16 / BF16X2 / FP16X2): slabs are
- * [part][tap][8-channel octet 0/1][co][8 x 16-bit] per 16 input channels, one part (rounded operands) or two
- * (hi + lo split); the size is returned in 4-byte units. */
+/* The same for the reduced-operand modes (precision = DVC_PRECISION_BF16 / BF16X2 / FP16X2), one part (rounded
+ * operands) or two (hi + lo split), per 16 input channels; the size is returned in 4-byte units.
+ * 1x1 and stride-2 layers: one slab per chunk, [part][tap][8-channel octet 0/1][co][8 x 16-bit].
+ * 3x3 / 7x7 stride-1 layers: one slab per (chunk, tap row), [part][kx][octet][co][8 x 16-bit] padded to whole
+ * 4 KiB -- the kernel walks K in (chunk, tap row) steps and DMAs a step's slab into a small LDS ring ahead of
+ * its use, so a 7x7 chunk's weights (200 KiB in two parts) are never resident at once. */
 int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
                                                 int32_t precision);
 int dvc_conv2d_reduced_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,

@@ -440,7 +440,9 @@ def test_bf16_precision_option(seeded_sd):
 
     bpp32, psnr32, rec32 = run()
     net.set_precision("bf16")
-    assert net.contextual_encoder.conv1._precision() and not net.optic_flow.moduleBasic[0].conv1._precision()
+    # every convolution but the flow / RGB heads (<= 4 output channels) takes the mode
+    assert net.contextual_encoder.conv1._precision() and net.optic_flow.moduleBasic[0].conv1._precision()
+    assert not net.optic_flow.moduleBasic[0].conv5._precision() and not net.recon_generation_net.recon_conv._precision()
     bpp16, psnr16, rec16 = run()
     assert not torch.equal(rec16[0], rec32[0])                 # it really is a different arithmetic
     assert abs(bpp16 - bpp32) <= 0.03 * bpp32, (bpp16, bpp32)

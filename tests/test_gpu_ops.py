@@ -411,6 +411,15 @@ BF16_CASES = [
     (3, 1, (24,), 32, 10, 14, 2, None, 0.01, True),
     (3, 1, (288,), 288, 17, 30, 1, None, 0.2, False),
     (3, 1, (64,), 64, 272, 480, 1, 0.01, 0.01, False),
+    (3, 1, (64, 64), 64, 544, 960, 1, None, 0.1, False),    # 8-row tiles of 64 channels, 8 chunks: the production variant
+    (3, 1, (16,), 32, 40, 70, 1, None, None, False),        # one chunk: the ring never fills
+    (3, 1, (40,), 64, 9, 33, 3, None, None, False),         # ragged last chunk (8 live channels), ragged tiles
+    (7, 1, (8,), 32, 30, 50, 1, None, 0.0, False),          # 7x7: half a chunk of channels
+    (7, 1, (32,), 64, 24, 40, 2, None, 0.0, False),
+    (7, 1, (64,), 32, 136, 240, 1, None, 0.0, False),
+    (7, 1, (32,), 16, 45, 37, 1, None, 0.0, False),
+    (7, 1, (32,), 64, 272, 480, 1, None, 0.0, False),       # 16-row tiles, one workgroup per CU
+    (7, 1, (64,), 32, 272, 480, 1, None, 0.0, False),
 ]
 
 
@@ -436,8 +445,6 @@ def test_conv2d_bf16_mode(k, stride, cins, cout, H, W, batch, in_slope, out_slop
     got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), stride=stride, in_slope=in_slope, out_slope=out_slope,
                      pixel_shuffle=shuffle, residual=dev(res), precision=1)
     close(got, want, rel=2e-5)
-    with pytest.raises(Exception):
-        ops.conv2d(dev(torch.randn(1, 8, 16, 16)), dev(torch.randn(8, 8, 7, 7)), None, precision=1)
 
 
 @pytest.mark.parametrize("mode", ["bf16x2", "fp16x2"])

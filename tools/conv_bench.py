@@ -66,7 +66,7 @@ def main():
         x = torch.randn(args.batch, cin, h, w, device="cuda")
         wt = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
-        bf = args.precision if k != 7 else 0
+        bf = args.precision if cout > 4 else 0
         if args.wgrad:
             ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
             g = torch.randn(args.batch, cout, ho, wo, device="cuda")

@@ -20,19 +20,24 @@ from deepvideocodec_amd import _lib, ops  # noqa: E402
 
 
 def main():
-    cin, cout, h, w = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (64, 64, 1088, 1920)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    prec = 0
+    for a in sys.argv[1:]:
+        if a.startswith("--precision="):
+            prec = int(a.split("=")[1])
+    cin, cout, h, w = (int(v) for v in args[:4]) if len(args) >= 4 else (64, 64, 1088, 1920)
     lib = _lib.load()
     lib.dvc_debug_conv_stamps.argtypes = [C.c_void_p]
     x = torch.randn(1, cin, h, w, device="cuda")
     wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
     b = torch.randn(cout, device="cuda")
-    packed = ops.pack_conv_weight(wt, 1)
-    out = ops.conv2d(x, wt, b, packed=packed)
+    packed = ops.pack_conv_weight(wt, 1, precision=prec)
+    out = ops.conv2d(x, wt, b, packed=packed, precision=prec)
     import time
     t_end = time.time() + 2.0   # two seconds of back-to-back launches: the clock has ramped up from idle by then
     while time.time() < t_end:
         for _ in range(20):
-            ops.conv2d(x, wt, b, packed=packed, out=out)
+            ops.conv2d(x, wt, b, packed=packed, out=out, precision=prec)
         torch.cuda.synchronize()
     n_wg = 1 << 16
     buf = torch.zeros(n_wg * 16, dtype=torch.int64, device="cuda")
@@ -40,7 +45,7 @@ def main():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.conv2d(x, wt, b, packed=packed, out=out)
+    ops.conv2d(x, wt, b, packed=packed, out=out, precision=prec)
     e1.record()
     torch.cuda.synchronize()
     lib.dvc_debug_conv_stamps(None)
@@ -59,7 +64,17 @@ def main():
           f"{(t[:, 1] - t[:, 0]).mean():.2f}, K loop {(t[:, 2] - t[:, 1]).mean():.2f}, epilogue {(t[:, 3] - t[:, 2]).mean():.2f}; "
           f"clock {np.median(cyc / np.maximum(dur, 1e-9)) / 1e3:.2f} GHz")
     tiles = st[:, 8:16].astype(np.float64) * 0.01 - t0
-    if os.environ.get("DVC_STAMP_CHUNKS"):
+    if os.environ.get("DVC_STAMP_CHUNKS") == "stepped":
+        # reduced-operand stepped K loop (library built with -DDVC_STAMP_CHUNKS): slots 8..15 are shader-clock stamps
+        # of the second chunk: before / after the MFMAs of tap rows 0, 1, 2; after the last row's wait; after its barrier
+        c = st[:, 8:16].astype(np.float64)
+        names = ["row 0 MFMAs", "row 0 end -> row 1 MFMAs (wait, barrier, requests)", "row 1 MFMAs",
+                 "row 1 end -> row 2 MFMAs (+ convert / commit next chunk)", "row 2 MFMAs", "row 2 wait", "row 2 barrier"]
+        segs = [c[:, i + 1] - c[:, i] for i in range(7)]
+        print("second K chunk of wave 0, shader cycles (mean / median / p90):")
+        for nm, sg in zip(names, segs):
+            print(f"  {nm:58s} {sg.mean():9.0f} {np.median(sg):9.0f} {np.percentile(sg, 90):9.0f}")
+    elif os.environ.get("DVC_STAMP_CHUNKS"):
         # library built with -DDVC_STAMP_CHUNKS: slots 8..15 are shader-clock stamps inside K chunks 2 and 3
         c = st[:, 8:16].astype(np.float64)
         names = ["start the next chunk's loads", "tap loop (MFMAs)", "commit rest of next chunk to LDS", "wait for DMA",
