@@ -105,11 +105,22 @@ struct Geo {
   // never have to be resident at once.  The converted input tile of a chunk stays for its KS steps; 3x3 keeps two of
   // them, so the next chunk is converted and written while the current one multiplies.
   static constexpr bool STEPPED = BF != 0 && KS != 1 && S == 1;
+  // Wave-specialised form of the largest split-operand 3x3 tile (16 rows x 32 pixels x 64 channels): a workgroup of
+  // EIGHT waves, one per CU.  Waves 0..3 only multiply (four rows of 32 pixels each, 128 accumulator registers, no
+  // staging registers); waves 4..7 only stage: they request the next chunk's weight slabs (DMA) and input tile,
+  // split the inputs into their 16-bit parts and write them to the other LDS buffer while the first four waves
+  // multiply the current chunk.  Each SIMD then holds one multiplying wave that has the matrix pipe to itself and
+  // one staging wave whose vector work runs beside it, with ONE barrier per chunk: the symmetric 4-wave form at two
+  // workgroups per CU kept the pipe about half busy (both workgroups of a CU are outside their multiply phases a
+  // quarter of the time, collide inside them another quarter, and a barrier per tap row waits for the slowest of
+  // four waves each time).
+  static constexpr bool WSP = BF >= 2 && KS == 3 && S == 1 && MT == 2 && NT == 4 && !HALF;
+  static constexpr int THREADS = WSP ? 512 : 256;
 #ifndef DVC_STEP_RING
 #define DVC_STEP_RING 2
 #endif
   static constexpr int NW = KS == 3 ? DVC_STEP_RING : 2;
-  static constexpr int NBUF = STEPPED ? (KS == 3 && DVC_STEP_RING == 3 ? 2 : 1) : (PARTS == 2 ? 1 : 2);   // LDS buffers of the input tile
+  static constexpr int NBUF = WSP ? 2 : STEPPED ? (KS == 3 && DVC_STEP_RING == 3 ? 2 : 1) : (PARTS == 2 ? 1 : 2);   // LDS buffers of the input tile
   static constexpr int CK = BF ? BF_CK : chunk_of(KS, S);
   static constexpr int TH = 4 * NT, TW = 32, CB = 32 * MT, PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
@@ -130,11 +141,11 @@ struct Geo {
   // step slab [part][kx][octet][co][8 x 16 bit] in 4-byte units, padded to whole 4 KiB (each of the four waves
   // moves the same number of 1 KiB pieces: the counted waits below rely on it)
   static constexpr int WSTEP = (PARTS * KS * 2 * CBP * 4 + 1023) / 1024 * 1024;
-  static constexpr int W_UNITS = STEPPED ? NW * WSTEP : NBUF * SLAB;   // LDS of the weights, 4-byte units
+  static constexpr int W_UNITS = WSP ? 2 * KS * WSTEP : STEPPED ? NW * WSTEP : NBUF * SLAB;   // LDS of the weights, 4-byte units
   static constexpr int STAGE_BYTES = (W_UNITS + NBUF * IN_BUF) * 4;
   // workgroups per CU the LDS allows (the register budget follows it)
   // (three per CU only where a wave's accumulators leave room in a 168-register budget: 64 of them at most)
-  static constexpr int MIN_WAVES = !STEPPED ? 2 : STAGE_BYTES > 80 * 1024 ? 1 : (STAGE_BYTES + 320 > 53 * 1024 || MT * NT > 4) ? 2 : 3;
+  static constexpr int MIN_WAVES = (!STEPPED || WSP) ? 2 : STAGE_BYTES > 80 * 1024 ? 1 : (STAGE_BYTES + 320 > 53 * 1024 || MT * NT > 4) ? 2 : 3;
   // four wave-private 32 x 36 transposition tiles + the four waves' per-channel sums (plane-sum output)
   static constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + 4 * 64 * 4;
   static constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
@@ -171,8 +182,16 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
       g_conv_stamps[wg_ * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
     }                                                                                                         \
   } while (0)
+#define DVC_CSTAMP_T(cond, slot, thread)                                                                      \
+  do {                                                                                                        \
+    if (g_conv_stamps != nullptr && threadIdx.x == (thread) && (cond)) {                                      \
+      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      g_conv_stamps[wg_ * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
+    }                                                                                                         \
+  } while (0)
 #else
 #define DVC_CSTAMP(cond, slot)
+#define DVC_CSTAMP_T(cond, slot, thread)
 #endif
 
 // s_barrier that the compiler may not move LDS accesses across (the bare builtin is not a memory operation for the
@@ -185,7 +204,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
-__global__ __launch_bounds__(256, (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES)) void conv_mfma_f32_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((Geo<KS, S, MT, NT, HALF, BF, DY>::THREADS), (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES))
+void conv_mfma_f32_kernel(const ConvArgs a) {
   using G = Geo<KS, S, MT, NT, HALF, BF, DY>;
   constexpr int CBP = G::CBP;
   constexpr int CK = G::CK, TH = G::TH, TW = G::TW, CB = G::CB, PAD = G::PAD, SL = G::SL, IW = G::IW, SLY = G::SLY;
@@ -197,9 +217,10 @@ __global__ __launch_bounds__(256, (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES))
   float* const in_s = lds + G::W_UNITS;     // [NBUF][IN_BUF]
   float* const bias_s = lds + G::MAIN_BYTES / 4;   // [CB] bias of this workgroup's channels (0 past Cout / without bias)
 
-  const int tid = threadIdx.x;
+  const int tid = G::WSP ? (int)(threadIdx.x & 255) : (int)threadIdx.x;   // index among the 256 staging (or multiplying) lanes
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // 0..3 within the wave's role
+  const bool stager = G::WSP && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // waves 4..7 of a wave-specialised workgroup
   DVC_STAMP(0);
   // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
   // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(256, (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES))
   if constexpr (DY > 1) {   // rows 16..31 are the 16 channels again
     if (tid < CB) bias_s[tid] = a.bias != nullptr ? a.bias[tid & 15] : 0.f;
   } else {
-    if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
+    if (tid < CB && !stager) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
   }
   const int n = blockIdx.z;
   const int nchunks = (a.cin + CK - 1) / CK;
@@ -440,7 +461,84 @@ __global__ __launch_bounds__(256, (Geo<KS, S, MT, NT, HALF, BF, DY>::MIN_WAVES))
   const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
   const int b_lane8 = half * CHS + (wave * NT * SL) * IW + l32 * SL;
 
-  if constexpr (G::STEPPED) {
+  if constexpr (G::WSP) {
+    // ---- wave-specialised K loop (see Geo::WSP): one barrier per chunk, taken by all eight waves
+    constexpr int WSTEP = G::WSTEP, WCH = KS * WSTEP;   // a chunk's three tap-row slabs are contiguous in the packed image
+    static_assert(WCH % 1024 == 0, "whole 1 KiB pieces per staging wave");
+    using V8 = typename Half16<G::F16>::V8;
+    if (stager) {
+      // One chunk per barrier interval: request the chunk's weight slabs (DMA) and input tile, split the input into
+      // its 16-bit parts, write it, wait until everything has landed.  Measured and not kept: requesting the input a
+      // whole interval ahead, and 16-byte input requests (a third of the request instructions) -- the staging waves
+      // spend their time waiting to ISSUE requests (about 220 cycles per request instruction): every chunk brings
+      // 36 KiB of weights and 40 KiB of input into the CU, and a CU's import rate (~12-15 bytes per cycle with all
+      // CUs streaming) makes that about as long as the chunk's 216 MFMAs; only fewer bytes per chunk would help.
+      auto stage = [&](int chunk) __attribute__((always_inline)) {
+        const int buf = chunk & 1;
+        float* dst = w_s + buf * WCH;
+        const unsigned soff = 4u * (unsigned)chunk * (unsigned)WCH;
+#pragma unroll
+        for (int p = 0; p < WCH / 1024; ++p) {
+          const int piece = wave + 4 * p;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                   16u * (unsigned)lane, soff + 1024u * (unsigned)piece, 0, 0);
+        }
+        prefetch_input(chunk * CK);
+        DVC_CSTAMP_T(chunk == 2, 14, 256);
+        commit_input(buf);
+        DVC_CSTAMP_T(chunk == 2, 15, 256);
+        __builtin_amdgcn_s_waitcnt(0x0070);   /* vmcnt(0) lgkmcnt(0): this wave's DMA pieces and LDS writes have landed */
+      };
+      stage(0);
+      lds_barrier();
+      for (int c = 0; c < nchunks; ++c) {
+        DVC_CSTAMP_T(c == 1, 11, 256);
+        if (c + 1 < nchunks) stage(c + 1);   // into the buffers the multiplying waves read during chunk c - 1
+        DVC_CSTAMP_T(c == 1, 12, 256);
+        lds_barrier();
+        DVC_CSTAMP_T(c == 1, 13, 256);
+      }
+      return;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): the bias values are in LDS */
+    lds_barrier();
+    DVC_STAMP(1);
+    constexpr int APART = KS * 2 * CBP, BPART = 2 * CHS;   // second operand part, in 16-byte units
+    for (int c = 0; c < nchunks; ++c) {
+      const int cur = c & 1;
+      const V8* const bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
+      const V8* const wbase = reinterpret_cast<const V8*>(w_s + cur * WCH) + a_lane8;
+      DVC_CSTAMP(c == 1, 8);
+#pragma unroll
+      for (int r = 0; r < KS; ++r) {
+        const V8* const abase = wbase + r * (WSTEP / 4);
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          V8 ah[MT], al[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = abase[kx * 2 * CBP + mt * 32];
+            al[mt] = abase[APART + kx * 2 * CBP + mt * 32];
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const V8 bh = bbase[(nt + r) * IW + kx];
+            const V8 bl = bbase[BPART + (nt + r) * IW + kx];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {   // the small cross terms first, then the leading one
+              acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
+              acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
+              acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave is done reading the chunk's buffers */
+      DVC_CSTAMP(c == 1, 9);
+      lds_barrier();
+      DVC_CSTAMP(c == 1, 10);
+    }
+  } else if constexpr (G::STEPPED) {
     // ---- K loop in steps of (chunk, tap row); see Geo::STEPPED.  Per step: [last row of a chunk: convert the next
     // chunk's input (requested during row 0) into the other input buffer] -> request the slab NW-1 steps ahead ->
     // [row 0: request the next chunk's input] -> the row's MFMAs -> wait until the NEXT step's slab has landed (all
@@ -1121,7 +1219,7 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
   b.sum_slots = b.tiles_x * tiles_y;
   dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>), grid, dim3(256), G::LDS_BYTES, st, b);
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>), grid, dim3(G::THREADS), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
 }
 
@@ -1163,7 +1261,8 @@ int dispatch_tile(const ConvArgs& a, int batch, hipStream_t st) {
   // stride 2 stages a (2*TH+1) x 65 halo per channel: 16-row tiles would not leave room for two
   // workgroups per CU, so those stop at 8 rows
   // (the split-operand 3x3 kernels hold two parts of every operand: 64 channels x 16 rows would spill)
-  constexpr bool WIDE_OK = !(S == 2 && KS != 1) && !(BF >= 2 && KS == 3);
+  // (except stride 1, where the 16-row tile is the wave-specialised form)
+  constexpr bool WIDE_OK = !(S == 2 && KS != 1) && !(BF >= 2 && KS == 3 && S != 1);
   // (a launch that emits plane sums picks its tile from one sample's tile count: see conv_plane_sum_slots)
   const int nt = pick_nt(a, a.plane_sums != nullptr ? 1 : batch, mt, S == 2 && KS != 1 ? 2 : (mt == 2 && !WIDE_OK) ? 2 : 4);
   if (mt == 2) {

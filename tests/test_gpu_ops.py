@@ -412,6 +412,10 @@ BF16_CASES = [
     (3, 1, (288,), 288, 17, 30, 1, None, 0.2, False),
     (3, 1, (64,), 64, 272, 480, 1, 0.01, 0.01, False),
     (3, 1, (64, 64), 64, 544, 960, 1, None, 0.1, False),    # 8-row tiles of 64 channels, 8 chunks: the production variant
+    (3, 1, (64,), 64, 544, 962, 1, None, None, False),      # width not a multiple of 4: 16-row form not available
+    (3, 1, (48, 3, 64), 128, 544, 960, 1, 0.1, None, False), # 16-row form: chunks straddling sources, ragged last chunk
+    (3, 1, (128,), 256, 272, 480, 1, None, None, True),     # 16-row form with the PixelShuffle store
+    (3, 1, (64,), 64, 1088, 1920, 1, None, 0.01, False),    # the benchmark's dominant layer
     (3, 1, (16,), 32, 40, 70, 1, None, None, False),        # one chunk: the ring never fills
     (3, 1, (40,), 64, 9, 33, 3, None, None, False),         # ragged last chunk (8 live channels), ragged tiles
     (7, 1, (8,), 32, 30, 50, 1, None, 0.0, False),          # 7x7: half a chunk of channels
