@@ -62,6 +62,7 @@ SIGNATURES = {
     "dvc_conv2d_plane_sum_slots": (_i32, [C.POINTER(DvcConv2d)]),
     "dvc_conv2d_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "dvc_conv2d_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _P, _P]),
+    "dvc_conv2d_pack_weight_dgrad": (C.c_int, [_P, _i32, _i32, _i32, _P, _P]),
     "dvc_conv2d_reduced_packed_weight_floats": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "dvc_conv2d_reduced_pack_weight": (C.c_int, [_P, _i32, _i32, _i32, _i32, _i32, _P, _P]),
     "dvc_flow_warp": (C.c_int, [_SRC, _SRC, _DST, _i32, _i32, _i32, _P]),

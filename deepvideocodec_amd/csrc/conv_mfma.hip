@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256) void pack_weight_step_kernel(const float* w, t
 }
 
 // OIHW -> [cout block][chunk][row = (ci - c0) * taps + tap][co - cb0], zero filled past Cin / Cout.
+// `dgrad`: the image of the data-gradient convolution's weight, W'[co][ci][ky][kx] = W[ci][co][k-1-ky][k-1-kx]
+// (cout / cin here are those of W': the input / output channels of the layer), read straight from the layer's OIHW
+// tensor -- no flipped / transposed copy is made.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* packed, int cout, int cin, int ks,
-                                                          int ck, int cb, int slab, int nchunks, long long total) {
+                                                          int ck, int cb, int slab, int nchunks, long long total, int dgrad) {
   const int taps = ks * ks;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int e = (int)(i % slab);
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
     const int ci = chunk * ck + row / taps, tap = row % taps;
     const int co = blk * cb + col;
     float v = 0.f;
-    if (row < ck * taps && ci < cin && co < cout) v = w[((long long)co * cin + ci) * taps + tap];
+    if (row < ck * taps && ci < cin && co < cout)
+      v = dgrad ? w[((long long)ci * cout + co) * taps + (taps - 1 - tap)] : w[((long long)co * cin + ci) * taps + tap];
     packed[i] = v;
   }
 }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
 // Row-pair image of a 7x7 layer with 16 output channels: [chunk][row = (ci - c0) * 56 + ky' * 7 + kx][32 columns],
 // column dy * 16 + co = w[co][ci][ky' - dy][kx] where that tap row exists, else 0.
 __global__ __launch_bounds__(256) void pack_weight_rowpair_kernel(const float* w, float* packed, int cin, int ck, int slab,
-                                                                  int nchunks, long long total) {
+                                                                  int nchunks, long long total, int dgrad) {
   constexpr int taps = dvc::CONV_ROWPAIR_TAPS;
   static_assert(dvc::CONV_ROWPAIR_COUT == 16, "column = dy * 16 + co");
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(256) void pack_weight_rowpair_kernel(const float* w
     const int kyp = tap / 7, kx = tap - kyp * 7;
     const int dy = col >> 4, co = col & 15, ky = kyp - dy;
     float v = 0.f;
-    if (row < ck * taps && ci < cin && ky >= 0 && ky < 7) v = w[((long long)co * cin + ci) * 49 + ky * 7 + kx];
+    if (row < ck * taps && ci < cin && ky >= 0 && ky < 7)
+      v = dgrad ? w[((long long)ci * 16 + co) * 49 + 48 - (ky * 7 + kx)] : w[((long long)co * cin + ci) * 49 + ky * 7 + kx];
     packed[i] = v;
   }
 }
@@ -135,8 +140,23 @@ extern "C" int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, in
   return total;
 }
 
+namespace {
+int pack_weight_impl(const float* weight, int32_t cout, int32_t cin, int32_t ksize, int32_t stride, float* packed, void* stream,
+                     int dgrad);
+}
 extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
                                       float* packed, void* stream) {
+  return pack_weight_impl(weight, cout, cin, ksize, stride, packed, stream, 0);
+}
+extern "C" int dvc_conv2d_pack_weight_dgrad(const float* weight, int32_t cout, int32_t cin, int32_t ksize, float* packed,
+                                            void* stream) {
+  // the data gradient of a layer with `cout` output and `cin` input channels is a stride-1 convolution with cin
+  // output and cout input channels
+  return pack_weight_impl(weight, cin, cout, ksize, 1, packed, stream, 1);
+}
+namespace {
+int pack_weight_impl(const float* weight, int32_t cout, int32_t cin, int32_t ksize, int32_t stride, float* packed, void* stream,
+                     int dgrad) {
   if (int rc = check_geometry(cout, cin, ksize, stride, "dvc_conv2d_pack_weight")) return rc;
   DVC_REQUIRE(weight != nullptr && packed != nullptr, "dvc_conv2d_pack_weight: null pointer");
   DVC_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "dvc_conv2d_pack_weight: packed buffer must be 16-byte aligned");
@@ -144,17 +164,18 @@ extern "C" int dvc_conv2d_pack_weight(const float* weight, int32_t cout, int32_t
   const int slab = slab_floats(ksize, stride, cb), nchunks = (cin + ck - 1) / ck;
   const long long total = (long long)((cout + cb - 1) / cb) * nchunks * slab;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(dvc::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                     packed, cout, cin, ksize, ck, cb, slab, nchunks, total);
+                     packed, cout, cin, ksize, ck, cb, slab, nchunks, total, dgrad);
   if (int rc = dvc::check_launch("pack_weight_kernel")) return rc;
   if (dvc::conv_has_rowpair_image(cout, ksize, stride)) {   // second image behind the first (see launch_rowpair)
     const int rslab = dvc::conv_rowpair_slab_floats();
     const long long rtotal = (long long)nchunks * rslab;
     hipLaunchKernelGGL(pack_weight_rowpair_kernel, dim3(dvc::stream_grid(rtotal, 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, packed + total, cin, ck, rslab, nchunks, rtotal);
+                       weight, packed + total, cin, ck, rslab, nchunks, rtotal, dgrad);
     return dvc::check_launch("pack_weight_rowpair_kernel");
   }
   return DVC_OK;
 }
+}  // namespace
 
 extern "C" int64_t dvc_conv2d_reduced_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride,
                                                            int32_t precision) {

@@ -53,6 +53,17 @@ class Conv2d(nn.Module):
             self._packed[precision] = hit
         return hit[1]
 
+    def dgrad_weight(self) -> Tensor:
+        """The kernel-layout image of the weight of this layer's data-gradient convolution (training): built once
+        per weight version, so the P frames of one step share it."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        hit = self._packed.get("dgrad")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_conv_weight_dgrad(w.detach().contiguous()))
+            self._packed["dgrad"] = hit
+        return hit[1]
+
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
                 pixel_shuffle=False, out=None, plane_sums=False):
         """`plane_sums=True` (inference only): returns (out, sums), see ops.conv2d."""
@@ -62,7 +73,7 @@ class Conv2d(nn.Module):
                 raise ValueError("Conv2d: `out=` is an inference-only option (call under torch.no_grad())")
             return A.conv2d(x, self.weight, self.bias, stride=self.stride, in_slope=in_slope, out_slope=out_slope,
                             residual=residual, res_scale=res_scale, residual2=residual2,
-                            pixel_shuffle=pixel_shuffle, packed=self.packed_weight())
+                            pixel_shuffle=pixel_shuffle, packed=self.packed_weight(), dgrad_packed=self.dgrad_weight())
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
                           pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._precision()),

@@ -108,6 +108,20 @@ def pack_conv_weight(weight: Tensor, stride: int = 1, precision: int = 0) -> Ten
     return packed
 
 
+def pack_conv_weight_dgrad(weight: Tensor) -> Tensor:
+    """The packed image of the weight of `weight`'s data-gradient convolution (flipped taps, channel axes swapped),
+    for conv2d(grad, (cin, cout, k, k), None, packed=...)."""
+    if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32 and weight.dim() == 4):
+        raise ValueError("pack_conv_weight_dgrad: weight must be a contiguous fp32 OIHW GPU tensor")
+    cout, cin, k, _ = weight.shape
+    lib = _lib.load()
+    n = check(lib.dvc_conv2d_packed_weight_floats(cin, cout, k, 1), "dvc_conv2d_packed_weight_floats")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib.dvc_conv2d_pack_weight_dgrad(weight.data_ptr(), cout, cin, k, packed.data_ptr(), _stream()),
+          "dvc_conv2d_pack_weight_dgrad")
+    return packed
+
+
 def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
            in_slope: Optional[float] = None, out_slope: Optional[float] = None,
            residual: Optional[Tensor] = None, res_scale: Optional[Tensor] = None,
@@ -133,25 +147,31 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
             raise ValueError(f"conv2d: source {i} shape {tuple(s.shape)} does not match {(n, '*', h, w)}")
         p.src[i] = _src(s, f"conv2d src[{i}]")
         cin += s.size(1)
-    cout, wcin, k, k2 = weight.shape
+    if isinstance(weight, torch.Tensor):
+        wshape, wdev = tuple(weight.shape), weight.device
+        if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32):
+            raise ValueError("conv2d: weight must be a contiguous fp32 GPU tensor")
+    else:   # only the layer's (Cout, Cin, k, k): the caller brings the packed image
+        wshape, wdev = tuple(weight), srcs[0].device
+        if packed is None:
+            raise ValueError("conv2d: a weight shape needs its packed image")
+    cout, wcin, k, k2 = wshape
     if wcin != cin or k != k2:
-        raise ValueError(f"conv2d: weight {tuple(weight.shape)} does not match {cin} input channels")
-    if not (weight.is_cuda and weight.is_contiguous() and weight.dtype == torch.float32):
-        raise ValueError("conv2d: weight must be a contiguous fp32 GPU tensor")
+        raise ValueError(f"conv2d: weight {wshape} does not match {cin} input channels")
     pad = k // 2
     ho = (h + 2 * pad - k) // stride + 1
     wo = (w + 2 * pad - k) // stride + 1
     oshape = (n, cout // 4, 2 * ho, 2 * wo) if pixel_shuffle else (n, cout, ho, wo)
     if out is None:
-        out = torch.empty(oshape, dtype=torch.float32, device=weight.device)
+        out = torch.empty(oshape, dtype=torch.float32, device=wdev)
     elif tuple(out.shape) != oshape:
         raise ValueError(f"conv2d: out shape {tuple(out.shape)} != {oshape}")
     p.n_src = len(srcs)
     p.batch, p.in_h, p.in_w = n, h, w
     if packed is None:
         packed = pack_conv_weight(weight, stride, precision=precision)
-    _check_vec(packed, None, "conv2d packed weight", device=weight.device)
-    _check_vec(bias, cout, "conv2d bias", device=weight.device)
+    _check_vec(packed, None, "conv2d packed weight", device=wdev)
+    _check_vec(bias, cout, "conv2d bias", device=wdev)
     p.weight_packed = packed.data_ptr()
     p.precision = int(precision)
     p.bias = _ptr(bias)
@@ -174,7 +194,7 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
     if res_scale is not None:
         if residual is None:
             raise ValueError("conv2d: res_scale needs a residual")
-        _check_vec(res_scale, n * oshape[1], "conv2d res_scale", device=weight.device)
+        _check_vec(res_scale, n * oshape[1], "conv2d res_scale", device=wdev)
         p.res_scale = res_scale.data_ptr()
     if residual2 is not None:
         if residual is None or tuple(residual2.shape) != oshape:
@@ -187,7 +207,7 @@ def conv2d(srcs: Srcs, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
     if plane_sums:
         slots = check(_lib.load().dvc_conv2d_plane_sum_slots(C.byref(p)), "dvc_conv2d_plane_sum_slots")
         if slots > 0:
-            sums = torch.empty((n, cout, slots), dtype=torch.float32, device=weight.device)
+            sums = torch.empty((n, cout, slots), dtype=torch.float32, device=wdev)
             p.plane_sums = sums.data_ptr()
     check(_lib.load().dvc_conv2d(C.byref(p), _stream()), "dvc_conv2d")
     return (out, sums) if plane_sums else out

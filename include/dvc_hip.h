@@ -121,6 +121,12 @@ int32_t dvc_conv2d_plane_sum_slots(const DvcConv2d* p);
 int64_t dvc_conv2d_packed_weight_floats(int32_t cout, int32_t cin, int32_t ksize, int32_t stride);
 int dvc_conv2d_pack_weight(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
                            int32_t stride, float* packed, void* stream);
+/* Image of the weight of the layer's DATA-GRADIENT convolution (training, dmc/train.py:329: loss.backward() through
+ * nn.Conv2d): the gradient w.r.t. the input of a layer with weight [cout][cin][k][k] is the stride-1 convolution of
+ * the (zero-upsampled, for stride 2) output gradient with W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx].  Packs W'
+ * straight from the layer's OIHW tensor; size = dvc_conv2d_packed_weight_floats(cin, cout, ksize, 1). */
+int dvc_conv2d_pack_weight_dgrad(const float* weight_oihw, int32_t cout, int32_t cin, int32_t ksize,
+                                 float* packed, void* stream);
 
 /* The same for the reduced-operand modes (precision = DVC_PRECISION_BF16 / BF16X2 / FP16X2), one part (rounded
  * operands) or two (hi + lo split), per 16 input channels; the size is returned in 4-byte units.

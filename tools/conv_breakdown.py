@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--precision", default="fp32", help="fp32 / bf16 / bf16x2 / fp16x2 (DMC.set_precision)")
     args = ap.parse_args()
     from bench import conv_variant
     from deepvideocodec_amd import ops
@@ -33,6 +34,7 @@ def main():
     net.load_state_dict(seeded_state_dict(seed=0))
     net = net.to(dev).eval()
     net.update(force=True)
+    net.set_precision(args.precision)
     if not args.overlap:
         video_model._DECODE_OVERLAP = False
     frames = [pad_to_multiple(f, 64).to(dev) for f in synthetic_gop(4, args.height, args.width, seed=5)]
