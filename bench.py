@@ -142,6 +142,7 @@ class ConvProbe:
         self.ops = ops
         self.orig = ops.conv2d
         self.orig_warp, self.orig_se = ops.flow_warp, ops.se_gate
+        self.orig_pool, self.orig_sums = ops.max_pool2, ops.se_gate_from_sums
         self.records = []
         self.hbm_records = []   # (kernel, algorithmic bytes, start event, end event) of the HBM-bound kernels
 
@@ -178,13 +179,21 @@ class ConvProbe:
 
         def probed_se(x, fc1, fc2):
             return bracket("se_gate (plane sums + gate)", 4.0 * x.numel(), self.orig_se, x, fc1, fc2)
+        def probed_pool(x):   # every input element once, a quarter as many outputs
+            return bracket("max_pool2", 4.0 * x.numel() * 1.25, self.orig_pool, x)
+
+        def probed_sums(sums, h, w, fc1, fc2):   # the per-tile sums the convolution's epilogue wrote, folded and gated
+            return bracket("se_gate_from_sums (fold of the conv epilogue's plane sums + gate)", 4.0 * sums.numel(),
+                           self.orig_sums, sums, h, w, fc1, fc2)
         self.ops.conv2d = probed
         self.ops.flow_warp, self.ops.se_gate = probed_warp, probed_se
+        self.ops.max_pool2, self.ops.se_gate_from_sums = probed_pool, probed_sums
         return self
 
     def __exit__(self, *a):
         self.ops.conv2d = self.orig
         self.ops.flow_warp, self.ops.se_gate = self.orig_warp, self.orig_se
+        self.ops.max_pool2, self.ops.se_gate_from_sums = self.orig_pool, self.orig_sums
 
     def hbm_summary(self):
         """Per HBM-bound kernel: launches, algorithmic bytes and achieved GB/s over the probed frames."""

@@ -8,7 +8,7 @@
 # written under gpurun_out/prof/ and copied to gpurun_out/profiles_TAG/ under the names profiles/ uses.
 set -e
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 P=$R/gpurun_out/profiles_$TAG
@@ -19,11 +19,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ben
 grep -h '^{' $O/bench.log | tail -1 > $P/${TAG}_bench.json
 cp $O/bench/bench_kernel_stats.csv $P/${TAG}_bench_kernel_stats.csv
 echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_g1 -o bench_g1 -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 > $O/bench_g1.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_g1 -o bench_g1 -- python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --training 0 > $O/bench_g1.log 2>&1
 grep -h '^{' $O/bench_g1.log | tail -1 > $P/${TAG}_bench_g1.json
 cp $O/bench_g1/bench_g1_kernel_stats.csv $P/${TAG}_bench_g1_kernel_stats.csv
 echo "bench_g1 done"
-PMC_CMD="python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --alt-precision none --steps 1 --warmup 0 --gop 3"
+PMC_CMD="python3 bench.py --gops-in-flight 1 --cpu-baseline 0 --training 0 --alt-precision none --steps 1 --warmup 0 --gop 3"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- $PMC_CMD > $O/pmc_fetch.log 2>&1
 echo "fetch pass done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- $PMC_CMD > $O/pmc_write.log 2>&1
@@ -46,6 +46,14 @@ with open(sys.argv[2], "w") as f:
             f.write(f"\"conv_mfma_f32_kernel{k}\",{len(v)},{c},{sum(v) / len(v):.1f}\n")
 EOF
 echo "mfma pass done"
+# the same counters for the 16-bit-operand (fp16 hi + lo) kernels of the dominant shapes: SQ_VALU_MFMA_BUSY_CYCLES counts
+# 32 cycles per v_mfma_f32_32x32x16_f16
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma16 -o mfma16 -- python3 tools/conv_bench.py --precision 3 --shapes main,main,c128_64,half128_256,k7_32_64 --iters 5 > $O/pmc_mfma16.log 2>&1
+python3 tools/pmc_mfma_summary.py "$O/pmc_mfma16/mfma16_counter_collection.csv" "$P/${TAG}_pmc_mfma_fp16x2.csv"
+echo "mfma16 pass done"
+timeout -k 10 200 python3 tools/conv_breakdown.py --top 60 > $P/${TAG}_conv_breakdown.txt 2>&1
+timeout -k 10 200 python3 tools/conv_breakdown.py --precision fp16x2 --top 60 > $P/${TAG}_conv_breakdown_fp16x2.txt 2>&1
+echo "breakdowns done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py --batch 32 --frames 3 --size 256 --steps 3 --warmup 1 > $O/train.log 2>&1
 grep -h '^{' $O/train.log | tail -1 > $P/${TAG}_train_b32.json
 cp $O/train/train_kernel_stats.csv $P/${TAG}_train_b32_kernel_stats.csv
