@@ -28,6 +28,9 @@ struct ConvArgs {
   int soff_ok;            // every source spans < 2 GiB per sample: a channel can be a 32-bit scalar offset
   float* plane_sums;      // optional [batch][cout][sum_slots]: per-workgroup sums of the stored output planes
   int sum_slots;          // workgroups per (sample, channel block) of this launch
+  // persistent (wave-specialised) launches: the grid is one workgroup per CU and each walks a range of the launch's
+  // work items, numbered (sample, channel block, tile) with the tile fastest
+  int tiles_xy, cblocks, total_items;
 };
 
 // fp32 packed weights (dvc_conv2d_pack_weight): input channels per K-chunk and floats per slab

@@ -159,7 +159,7 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #define DVC_STAMP(k)                                                                                          \
   do {                                                                                                        \
     if (g_conv_stamps != nullptr && threadIdx.x == 0) {                                                       \
-      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      const unsigned long long wg_ = stamp_wg; \
       g_conv_stamps[wg_ * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                       \
       if ((k) == 0) {                                                                                         \
         g_conv_stamps[wg_ * 16 + 4] = __builtin_amdgcn_s_memtime();                                           \
@@ -178,14 +178,14 @@ __device__ unsigned long long* g_conv_stamps = nullptr;
 #define DVC_CSTAMP(cond, slot)                                                                                \
   do {                                                                                                        \
     if (g_conv_stamps != nullptr && threadIdx.x == 0 && (cond)) {                                             \
-      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      const unsigned long long wg_ = stamp_wg; \
       g_conv_stamps[wg_ * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
     }                                                                                                         \
   } while (0)
 #define DVC_CSTAMP_T(cond, slot, thread)                                                                      \
   do {                                                                                                        \
     if (g_conv_stamps != nullptr && threadIdx.x == (thread) && (cond)) {                                      \
-      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      const unsigned long long wg_ = stamp_wg; \
       g_conv_stamps[wg_ * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                        \
     }                                                                                                         \
   } while (0)
@@ -221,13 +221,66 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
   const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // 0..3 within the wave's role
   const bool stager = G::WSP && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // waves 4..7 of a wave-specialised workgroup
-  DVC_STAMP(0);
-  // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
-  // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
-  // of them: the halo columns and rows shared by neighbouring tiles are then fetched into one L2
-  // once instead of into up to three.  (Any launch order gives correct results; this is locality.)
-  int tile;
-  {
+#ifdef DVC_CONV_STAMPS
+  // record index of the stamps: the workgroup, or (persistent form) workgroups x tiles walked so far + workgroup
+  unsigned long long stamp_wg = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#define DVC_STAMP_NEXT_TILE() (stamp_wg += gridDim.x)
+#else
+#define DVC_STAMP_NEXT_TILE()
+#endif
+  if constexpr (!G::WSP) DVC_STAMP(0);
+  // ---- per-tile state.  A workgroup computes one tile (set once from its block index), or -- wave-specialised
+  // form -- walks a list of them (set again per tile, by each wave role at its own pace).
+  int tile = 0, n = 0, wblock = 0, cb0 = 0, oy0 = 0, ox0 = 0;
+  const int nchunks = (a.cin + CK - 1) / CK;
+  // byte offset of each staged element inside its channel plane; padding elements get an offset
+  // past every plane, for which the buffer load returns 0 (hardware range check) -- zero padding
+  // and the ragged last channel chunk cost no select instructions.
+  unsigned in_boff[IN_PT];
+  const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
+  const float* wslabs = a.wpacked;
+  // The (up to 4) concatenated sources, hoisted out of the kernel-argument segment once (plain
+  // scalars, not arrays: resolving a channel to its plane inside the K loop must cost neither
+  // dependent scalar loads nor scratch traffic).
+  // (unused sources have channels == 0 and a null pointer: they are never selected)
+  const float *sp0 = nullptr, *sp1 = nullptr, *sp2 = nullptr, *sp3 = nullptr;
+  // global -> LDS DMA of weight slabs is issued as buffer loads (MUBUF ... lds), not global_load_lds: the compiler
+  // treats a FLAT-family instruction that touches LDS as able to return out of order with the ds_reads and then
+  // waits for lgkmcnt(0) before every MFMA group, which exposes the LDS latency of the operand reads just issued
+  // for the next tap (10 % of the K loop for a wave alone on its SIMD).
+  __amdgpu_buffer_rsrc_t wrsrc;
+  auto set_tile = [&](int tile_, int by, int bz) __attribute__((always_inline)) {
+    tile = tile_;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    oy0 = ty * TH;
+    ox0 = tx * TW;
+    wblock = HALF ? (by >> 1) : by;   // packed weight block
+    cb0 = HALF ? wblock * 64 + (by & 1) * 32 : wblock * CB;
+    n = bz;
+    // per-thread staging descriptors (identical for every channel and chunk)
+    const int gy0 = (KS == 1) ? oy0 * S : oy0 * (DY > 1 ? DY : S) - PAD;   // (row pairs: oy0 counts pairs)
+    const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
+#pragma unroll
+    for (int j = 0; j < IN_PT; ++j) {
+      const int i = tid + 256 * j;
+      const int iy = i / IW, ix = i - iy * IW;
+      const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
+      const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
+    }
+    wslabs = a.wpacked + (long long)wblock * nchunks * (G::STEPPED ? KS * G::WSTEP : SLAB);
+    wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)(G::STEPPED ? KS * G::WSTEP : SLAB)), 0x00020000);
+    sp0 = a.src[0].ptr + (long long)n * a.src[0].batch_stride;
+    sp1 = a.src[1].ptr + (long long)n * a.src[1].batch_stride;
+    sp2 = a.src[2].ptr + (long long)n * a.src[2].batch_stride;
+    sp3 = a.src[3].ptr + (long long)n * a.src[3].batch_stride;
+  };
+  if constexpr (!G::WSP) {
+    // Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its own L2.
+    // Tiles are therefore renumbered so that each XCD works through one contiguous row-major range
+    // of them: the halo columns and rows shared by neighbouring tiles are then fetched into one L2
+    // once instead of into up to three.  (Any launch order gives correct results; this is locality.)
     const int nt = gridDim.x;
     const int s = (int)((blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x) & 7;   // XCD phase of this grid row
     const int u = blockIdx.x + s, k = u & 7;
@@ -235,48 +288,18 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     const int m1 = s + nt;
     const int before = (m1 >> 3) * k + min(m1 & 7, k) - min(s, k);
     const int first_u = s + ((k - s) & 7);
-    tile = before + ((u - first_u) >> 3);
+    set_tile(before + ((u - first_u) >> 3), (int)blockIdx.y, (int)blockIdx.z);
+    if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
+    if constexpr (DY > 1) {   // rows 16..31 are the 16 channels again
+      if (tid < CB) bias_s[tid] = a.bias != nullptr ? a.bias[tid & 15] : 0.f;
+    } else {
+      if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
+    }
   }
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int wblock = HALF ? (int)(blockIdx.y >> 1) : (int)blockIdx.y;   // packed weight block
-  const int cb0 = HALF ? wblock * 64 + (int)(blockIdx.y & 1) * 32 : wblock * CB;
-  if (HALF && cb0 >= a.cout) return;   // upper half of a ragged last block: nothing to compute (workgroup-uniform)
-  if constexpr (DY > 1) {   // rows 16..31 are the 16 channels again
-    if (tid < CB) bias_s[tid] = a.bias != nullptr ? a.bias[tid & 15] : 0.f;
-  } else {
-    if (tid < CB && !stager) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
-  }
-  const int n = blockIdx.z;
-  const int nchunks = (a.cin + CK - 1) / CK;
-
-  // ---- per-thread staging descriptors (identical for every channel and chunk)
-  const int gy0 = (KS == 1) ? oy0 * S : oy0 * (DY > 1 ? DY : S) - PAD;   // (row pairs: oy0 counts pairs)
-  const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
-  // byte offset of each staged element inside its channel plane; padding elements get an offset
-  // past every plane, for which the buffer load returns 0 (hardware range check) -- zero padding
-  // and the ragged last channel chunk cost no select instructions.
-  unsigned in_boff[IN_PT];
-#pragma unroll
-  for (int j = 0; j < IN_PT; ++j) {
-    const int i = tid + 256 * j;
-    const int iy = i / IW, ix = i - iy * IW;
-    const int gy = gy0 + iy * GS, gx = gx0 + ix * GS;
-    const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    in_boff[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
-  }
-  const unsigned plane_bytes = 4u * (unsigned)(a.h * a.w);
-  const float* wslabs = a.wpacked + (long long)wblock * nchunks * (G::STEPPED ? KS * G::WSTEP : SLAB);
 
   float rin[CK][IN_PT];
 
   // global -> LDS DMA of one weight slab: SLAB/256 pieces of 1 KiB, round-robin over the 4 waves.
-  // Issued as buffer loads (MUBUF ... lds), not global_load_lds: the compiler treats a FLAT-family
-  // instruction that touches LDS as able to return out of order with the ds_reads and then waits for
-  // lgkmcnt(0) before every MFMA group, which exposes the LDS latency of the operand reads just issued
-  // for the next tap (10 % of the K loop for a wave alone on its SIMD).
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(wslabs), 0, (unsigned)(4u * (unsigned)nchunks * (unsigned)(G::STEPPED ? KS * G::WSTEP : SLAB)), 0x00020000);
   auto dma_weights = [&](int chunk, int buf) __attribute__((always_inline)) {
     float* dst = w_s + buf * SLAB;
     const unsigned soff = 4u * (unsigned)chunk * (unsigned)SLAB;
@@ -289,14 +312,6 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     }
   };
 
-  // The (up to 4) concatenated sources, hoisted out of the kernel-argument segment once (plain
-  // scalars, not arrays: resolving a channel to its plane inside the K loop must cost neither
-  // dependent scalar loads nor scratch traffic).
-  // (unused sources have channels == 0 and a null pointer: they are never selected)
-  const float* const sp0 = a.src[0].ptr + (long long)n * a.src[0].batch_stride;
-  const float* const sp1 = a.src[1].ptr + (long long)n * a.src[1].batch_stride;
-  const float* const sp2 = a.src[2].ptr + (long long)n * a.src[2].batch_stride;
-  const float* const sp3 = a.src[3].ptr + (long long)n * a.src[3].batch_stride;
   const long long cs0 = a.src[0].chan_stride, cs1 = a.src[1].chan_stride;
   const long long cs2 = a.src[2].chan_stride, cs3 = a.src[3].chan_stride;
   const int e0 = a.src[0].channels;   // first channel past source 0, 1, 2
@@ -319,7 +334,8 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
   struct Fetch { unsigned lo, hi, cs4, soff0; bool fast; };
   // Starts the fetch of chunk c0: works out the common-case state, or (chunk straddling sources / running past
   // the last channel) issues all of the chunk's loads with one descriptor per channel and returns fast = false.
-  auto prefetch_begin = [&](int c0) __attribute__((always_inline)) -> Fetch {
+  // (`issue(descriptor, scalar offset, channel index constant)` requests one channel of the chunk for this lane)
+  auto prefetch_begin_with = [&](int c0, auto&& issue) __attribute__((always_inline)) -> Fetch {
     const int cl = c0 + CK - 1;
     const unsigned long long b0 = reinterpret_cast<unsigned long long>(sp0);
     const unsigned long long b1 = reinterpret_cast<unsigned long long>(sp1);
@@ -366,22 +382,31 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
       const unsigned nbytes = __builtin_amdgcn_readfirstlane(have ? plane_bytes : 0u);
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nbytes, 0x00020000);
-#pragma unroll
-      for (int j = 0; j < IN_PT; ++j)
-        rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], 0, 0));
+      issue(rsrc, 0u, cc);
     });
     return Fetch{0u, 0u, 0u, 0u, false};
+  };
+  auto issue_dwords = [&](const __amdgpu_buffer_rsrc_t rsrc, unsigned soff, auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+#pragma unroll
+    for (int j = 0; j < IN_PT; ++j)
+      rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
+  };
+  auto prefetch_begin = [&](int c0) __attribute__((always_inline)) -> Fetch { return prefetch_begin_with(c0, issue_dwords); };
+  // the common case's descriptor of channel c of the chunk and the scalar offset that goes with it
+  auto channel_rsrc = [&](const Fetch& f, unsigned soff) __attribute__((always_inline)) {
+    // the range check compares the per-lane offset with (records - scalar offset): records end
+    // with this channel's plane
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)f.hi << 32) | f.lo), 0, soff + plane_bytes, 0x00020000);
   };
   // Common case (the chunk lies inside one source and inside cin): one buffer descriptor on the source's sample,
   // the channel as the scalar offset operand of the load (not part of the range check, which keeps working per
   // plane through the per-lane offsets) -- a couple of scalar instructions per channel and no branches, so a
   // channel's loads fit between two MFMAs of the current chunk.
   auto prefetch_channel = [&](const Fetch& f, int c) __attribute__((always_inline)) {
-    // the range check compares the per-lane offset with (records - scalar offset): records end
-    // with this channel's plane
     const unsigned soff = f.soff0 + (unsigned)c * f.cs4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(((unsigned long long)f.hi << 32) | f.lo), 0, soff + plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = channel_rsrc(f, soff);
 #pragma unroll
     for (int j = 0; j < IN_PT; ++j)
       rin[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, in_boff[j], soff, 0));
@@ -461,83 +486,617 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
   const int a_lane8 = half * CBP + l32 + (HALF ? 32 * (int)(blockIdx.y & 1) : 0);
   const int b_lane8 = half * CHS + (wave * NT * SL) * IW + l32 * SL;
 
-  if constexpr (G::WSP) {
-    // ---- wave-specialised K loop (see Geo::WSP): one barrier per chunk, taken by all eight waves
-    constexpr int WSTEP = G::WSTEP, WCH = KS * WSTEP;   // a chunk's three tap-row slabs are contiguous in the packed image
-    static_assert(WCH % 1024 == 0, "whole 1 KiB pieces per staging wave");
-    using V8 = typename Half16<G::F16>::V8;
-    if (stager) {
-      // One chunk per barrier interval: request the chunk's weight slabs (DMA) and input tile, split the input into
-      // its 16-bit parts, write it, wait until everything has landed.  Measured and not kept: requesting the input a
-      // whole interval ahead, and 16-byte input requests (a third of the request instructions) -- the staging waves
-      // spend their time waiting to ISSUE requests (about 220 cycles per request instruction): every chunk brings
-      // 36 KiB of weights and 40 KiB of input into the CU, and a CU's import rate (~12-15 bytes per cycle with all
-      // CUs streaming) makes that about as long as the chunk's 216 MFMAs; only fewer bytes per chunk would help.
-      auto stage = [&](int chunk) __attribute__((always_inline)) {
-        const int buf = chunk & 1;
-        float* dst = w_s + buf * WCH;
-        const unsigned soff = 4u * (unsigned)chunk * (unsigned)WCH;
+  // ---- the tile's epilogue (run once the K loop is done; `epi`: LDS the transposition tiles may use)
+  // (the lane coordinates are parameters so that the persistent form can hand in copies the optimiser cannot trace:
+  // the per-lane store offsets would otherwise be hoisted out of the tile loop and held across the K loop)
+  auto epilogue = [&](float* const epi, const int lane, const int half, const int l32) __attribute__((always_inline)) {
+  DVC_STAMP(2);
+#ifdef DVC_EXP_NO_EPILOGUE   // experiment: how long the launch takes with no epilogue at all (wrong results)
+  if (a.h < 0) {
+    float sacc = 0.f;
+    for (int mt = 0; mt < MT; ++mt) for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
+    a.out[tid] = sacc;
+  }
+  return;
+#endif
+  // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
+  // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
+  // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
+  // 128 stores of a lane cost no 64-bit vector address arithmetic.
+  const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
+  float* const out_n = a.out + (long long)n * a.obs;
+  const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
+  const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
+
+  if constexpr (DY > 1) {
+    // Row pairs (launched only for sizes the tile divides, 16-byte aligned rows, no residual / shuffle): rows
+    // 0..15 of an accumulator tile are output row 2p, rows 16..31 output row 2p + 1 of channels 0..15.  The same
+    // trip through the wave's LDS tile as below; piece q of a lane = channel 8 (q & 1) + sub of row 2p + (q >> 1).
+    constexpr int RS = 36;
+    float* const tl = epi + wave * (32 * RS);
+    const int sub = lane >> 3, px4 = 4 * (lane & 7);
+    const unsigned o_lane = (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
+    const int lds_lane = sub * RS + px4;
+    const float out_slope = a.out_slope;
+    float4 cur[4];
+    float bias_r[16];
 #pragma unroll
-        for (int p = 0; p < WCH / 1024; ++p) {
-          const int piece = wave + 4 * p;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
-                                                   16u * (unsigned)lane, soff + 1024u * (unsigned)piece, 0, 0);
+    for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[4 * half + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int i = 0; i <= NT; ++i) {
+      if (i < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = f32x2{acc[0][i][r], acc[0][i][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
+          const f32x2 sv = v * out_slope;
+          tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
+          tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
         }
-        prefetch_input(chunk * CK);
-        DVC_CSTAMP_T(chunk == 2, 14, 256);
-        commit_input(buf);
-        DVC_CSTAMP_T(chunk == 2, 15, 256);
-        __builtin_amdgcn_s_waitcnt(0x0070);   /* vmcnt(0) lgkmcnt(0): this wave's DMA pieces and LDS writes have landed */
-      };
-      stage(0);
-      lds_barrier();
-      for (int c = 0; c < nchunks; ++c) {
-        DVC_CSTAMP_T(c == 1, 11, 256);
-        if (c + 1 < nchunks) stage(c + 1);   // into the buffers the multiplying waves read during chunk c - 1
-        DVC_CSTAMP_T(c == 1, 12, 256);
-        lds_barrier();
-        DVC_CSTAMP_T(c == 1, 13, 256);
       }
-      return;
+      if (i > 0) {
+        const long long row0 = 2LL * (oy0 + wave * NT + (i - 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(out_n + (long long)(8 * (q & 1)) * a.ocs + (row0 + (q >> 1)) * a.wo + ox0 + o_lane) = cur[q];
+      }
+      if (i < NT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): the bias values are in LDS */
-    lds_barrier();
-    DVC_STAMP(1);
-    constexpr int APART = KS * 2 * CBP, BPART = 2 * CHS;   // second operand part, in 16-byte units
-    for (int c = 0; c < nchunks; ++c) {
-      const int cur = c & 1;
-      const V8* const bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
-      const V8* const wbase = reinterpret_cast<const V8*>(w_s + cur * WCH) + a_lane8;
-      DVC_CSTAMP(c == 1, 8);
+    DVC_STAMP(3);
+    return;
+  }
+  if (a.vec4) {
+    // Fast path (everything 16-byte aligned).  Store instructions, not bytes, are what the epilogue
+    // pays for, so each 32 channel x 32 pixel accumulator tile is turned through a wave-private LDS
+    // tile ([channel][pixel], row stride RS) and leaves as 16-byte stores: 4 per lane instead of 16.
+    // All waves are past the K loop's last barrier, so the staging buffers are free; a wave's LDS
+    // instructions execute in order, so its reads see its own writes without a barrier.
+    // The code is instantiated per residual configuration so that a tile is straight-line code: the
+    // residual loads of a tile are issued before its trip through LDS and are waited for only at the add.
+    constexpr int RS = 36;
+    static_assert(G::LDS_BYTES >= 4 * 32 * RS * 4, "epilogue tiles do not fit the staging buffers");
+    float* const tl = epi + wave * (32 * RS);
+    auto run = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c) {
+      constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
+      constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
+      // plain: 8 lanes x 16 B per channel row, quad q covers channels 8q + sub
+      // shuffle: conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)): an output
+      // row interleaves two adjacent conv channels; 16 lanes x 16 B per output row, a lane takes 2 pixels of
+      // both channels = 4 outputs; quad q covers output rows 4q + row of the tile (row = (channel, dy))
+      const int sub = lane >> 3, px4 = 4 * (lane & 7);
+      const int row = lane >> 4, px2 = 2 * (lane & 15);
+      const long long wo2 = 2LL * a.wo;
 #pragma unroll
-      for (int r = 0; r < KS; ++r) {
-        const V8* const abase = wbase + r * (WSTEP / 4);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int cu0 = cb0 + mt * 32;
+        float bias_r[16];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          V8 ah[MT], al[MT];
+        for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            ah[mt] = abase[kx * 2 * CBP + mt * 32];
-            al[mt] = abase[APART + kx * 2 * CBP + mt * 32];
+        for (int nt = 0; nt < NT; ++nt) {
+          const int oy = oy0 + wave * NT + nt;
+          if (oy >= a.ho) continue;   // wave-uniform
+          // where the four 16-byte pieces of this lane go (stored-tensor channel, pixel offset)
+          bool ok[4];
+          int chs[4];
+          long long pix[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (!PS) {
+              chs[q] = cu0 + 8 * q + sub;
+              ok[q] = chs[q] < a.cout && ox0 + px4 < a.wo;
+              pix[q] = (long long)oy * a.wo + ox0 + px4;
+            } else {
+              const int rr = 4 * q + row, c2l = rr >> 1, dy = rr & 1;
+              chs[q] = (cu0 >> 2) + c2l;
+              ok[q] = cu0 + 4 * c2l + 2 * dy < a.cout && ox0 + px2 < a.wo;
+              pix[q] = (2LL * oy + dy) * wo2 + 2 * (ox0 + px2);
+            }
+          }
+          float4 t[4], u[4];
+          float sc[4];
+          if constexpr (RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // lanes without a piece read the sample's first 16 bytes
+              t[q] = *reinterpret_cast<const float4*>(res_n + (ok[q] ? chs[q] * a.rcs + pix[q] : 0LL));
+              if constexpr (RES2) u[q] = *reinterpret_cast<const float4*>(res2_n + (ok[q] ? chs[q] * a.r2cs + pix[q] : 0LL));
+              if constexpr (SCALE) sc[q] = a.res_scale[n * a.c_final + (ok[q] ? chs[q] : 0)];
+            }
           }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const V8 bh = bbase[(nt + r) * IW + kx];
-            const V8 bl = bbase[BPART + (nt + r) * IW + kx];
+          for (int r = 0; r < 16; ++r)
+            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = dvc::leaky(acc[mt][nt][r] + bias_r[r], a.out_slope);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {   // the small cross terms first, then the leading one
-              acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
-              acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
-              acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
+          for (int q = 0; q < 4; ++q) {
+            float4 v;
+            if constexpr (!PS) {
+              v = *reinterpret_cast<const float4*>(tl + (8 * q + sub) * RS + px4);
+            } else {
+              const int rr = 4 * q + row, chl = 4 * (rr >> 1) + 2 * (rr & 1);
+              const float2 e = *reinterpret_cast<const float2*>(tl + chl * RS + px2);
+              const float2 o = *reinterpret_cast<const float2*>(tl + (chl + 1) * RS + px2);
+              v = make_float4(e.x, o.x, e.y, o.y);
+            }
+            if constexpr (RES) {
+              if constexpr (SCALE) {
+                // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
+                v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, sc[q])); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, sc[q]));
+                v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, sc[q])); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, sc[q]));
+              } else {
+                v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
+              }
+              if constexpr (RES2) { v.x += u[q].x; v.y += u[q].y; v.z += u[q].z; v.w += u[q].w; }
+            }
+            if (ok[q]) *reinterpret_cast<float4*>(out_n + chs[q] * a.ocs + pix[q]) = v;
+          }
+#ifndef DVC_STAMP_CHUNKS
+          DVC_STAMP(8 + ((mt * NT + nt) & 7));
+#endif
+        }
+      }
+    };
+    // The common case -- no PixelShuffle, the whole 32*MT x TH x 32 tile inside the tensor -- as one
+    // branch-free software pipeline over the MT*NT accumulator tiles of the wave: tile i is written to the
+    // wave's LDS tile and read back transposed, and while those reads are in flight tile i-1 gets its
+    // residuals added and is stored (LDS executes a wave's accesses in order, so the single tile buffer
+    // needs no waits between tiles).  Addresses are a wave-uniform base per (tile, channel octet) plus one
+    // 32-bit per-lane offset computed once; the bias comes from LDS.
+    auto run_full = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c, auto sums_c) {
+      constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
+      constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
+      // SUMS: also emit, per output channel, the sum of the values this workgroup stores (the first stage of a
+      // deterministic two-stage plane sum: the squeeze-excite gate needs the plane means of this very tensor, and
+      // a separate pass would read all of it back from HBM)
+      constexpr bool SUMS = decltype(sums_c)::value;
+      static_assert(!SUMS || (!RES && !PS), "plane sums: plain stores without residual");
+      float psum[MT][4];
+      if constexpr (SUMS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) psum[mt][q] = 0.f;
+      }
+      // plain: 8 lanes x 16 B per channel row; piece q of a lane = channel 8q + sub, pixels px4 .. px4+3.
+      // shuffle: conv channel co -> stored channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); 16 lanes x 16 B
+      // per stored row; piece q = stored channel 2q + (row>>1), row parity row&1, conv pixels px2, px2+1 of the
+      // two conv channels 8q + 4(row>>1) + 2(row&1) + {0, 1}.
+      const int sub = lane >> 3, px4 = 4 * (lane & 7);
+      const int row = lane >> 4, px2 = 2 * (lane & 15);
+      const long long wo2 = 2LL * a.wo;
+      const unsigned o_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.ocs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                 : (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
+      const unsigned r_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.rcs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                 : (unsigned)sub * (unsigned)a.rcs + (unsigned)px4;
+      const unsigned r2_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.r2cs + (unsigned)((row & 1) * wo2) + 2u * px2
+                                  : (unsigned)sub * (unsigned)a.r2cs + (unsigned)px4;
+      const int lds_lane = PS ? (4 * (row >> 1) + 2 * (row & 1)) * RS + px2 : sub * RS + px4;
+      const int cq = PS ? 2 : 8;             // stored channels per piece index q
+      const int c0s = PS ? (cb0 >> 2) : cb0;   // first stored channel of the workgroup
+      const int cms = PS ? 8 : 32;           // stored channels per 32-channel accumulator group
+      const float out_slope = a.out_slope;
+      float4 cur[4], t[4];
+      float4 t2[(RES2 && G::WSP) ? 4 : 1];
+      float bias_r[16];
+      float sc[MT][4];
+      if constexpr (SCALE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            sc[mt][q] = a.res_scale[n * a.c_final + c0s + mt * cms + cq * q + (PS ? (row >> 1) : sub)];
+      }
+      auto tile_pix = [&](int nt) -> long long {   // wave-uniform pixel offset of the tile inside a stored plane
+        const long long oy = oy0 + wave * NT + nt;
+        return PS ? 2 * oy * wo2 + 2LL * ox0 : oy * a.wo + ox0;
+      };
+      auto finish = [&](int mt, int nt) {   // residual adds + stores of a tile whose transposed values are in `cur`
+        const long long pix = tile_pix(nt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = cur[q];
+          const long long ch = c0s + mt * cms + cq * q;   // wave-uniform stored channel of this piece (lane 0's)
+          if constexpr (RES) {
+            if constexpr (SCALE) {
+              // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
+              const float g = sc[mt][q];
+              v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, g)); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, g));
+              v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, g)); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, g));
+            } else {
+              v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
+            }
+            if constexpr (RES2) {
+              // (rare: loaded where it is used, to stay within the register budget -- except in the one-workgroup-per-CU
+              // form, where no other workgroup hides the wait and the operand is requested a tile ahead like `t`)
+              float4 u;
+              if constexpr (G::WSP) u = t2[q];
+              else u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix + r2_lane);
+              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+          }
+          *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix + o_lane) = v;
+          if constexpr (SUMS) psum[mt][q] += (v.x + v.y) + (v.z + v.w);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i <= MT * NT; ++i) {
+        if (i < MT * NT) {
+          const int mt = i / NT, nt = i - mt * NT;
+          if (nt == 0) {   // one batch of LDS reads per 32-channel group (not one dependent read per value)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {   // two values per instruction (v_pk_add_f32, v_pk_mul_f32)
+            const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
+            const f32x2 sv = v * out_slope;
+            // LeakyReLU / ReLU / identity (slope 1) as max(v, v * slope): equal to the select for 0 <= slope <= 1
+            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
+            tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
+          }
+        }
+        if (i > 0) finish((i - 1) / NT, (i - 1) % NT);
+        if (i < MT * NT) {
+          const int mt = i / NT, nt = i - mt * NT;
+          // read tile i back transposed; consumed one iteration later, behind the next tile's arithmetic
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (!PS) {
+              cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
+            } else {
+              const float2 e = *reinterpret_cast<const float2*>(tl + 8 * q * RS + lds_lane);
+              const float2 o = *reinterpret_cast<const float2*>(tl + (8 * q + 1) * RS + lds_lane);
+              cur[q] = make_float4(e.x, o.x, e.y, o.y);
+            }
+          }
+          if constexpr (RES) {   // this tile's residual operands, consumed one iteration later as well
+            const long long pix = tile_pix(nt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              t[q] = *reinterpret_cast<const float4*>(res_n + (long long)(c0s + mt * cms + cq * q) * a.rcs + pix + r_lane);
+              if constexpr (RES2 && G::WSP)
+                t2[q] = *reinterpret_cast<const float4*>(res2_n + (long long)(c0s + mt * cms + cq * q) * a.r2cs + pix + r2_lane);
             }
           }
         }
       }
-      __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave is done reading the chunk's buffers */
-      DVC_CSTAMP(c == 1, 9);
-      lds_barrier();
-      DVC_CSTAMP(c == 1, 10);
+      if constexpr (SUMS) {
+        // a lane's psum[mt][q] covers 4 pixels x NT rows of channel 32 mt + 8 q + sub; the 8 lanes of a channel
+        // are adjacent: fold them, then the four waves through LDS, always in the same order
+        float* const red = epi + 4 * (32 * RS);   // [wave][CB], behind the transposition tiles
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float s = psum[mt][q];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if ((lane & 7) == 0) red[wave * CB + mt * 32 + 8 * q + sub] = s;
+          }
+        __syncthreads();
+        if (tid < CB)
+          a.plane_sums[((long long)n * a.cout + cb0 + tid) * a.sum_slots + tile] =
+              (red[tid] + red[CB + tid]) + (red[2 * CB + tid] + red[3 * CB + tid]);
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    // (slopes outside [0, 1] never occur in the DMC graph; they take the general formulation below)
+    const bool full = cb0 + CB <= a.cout && ox0 + TW <= a.wo && oy0 + TH <= a.ho &&
+                      a.out_slope >= 0.f && a.out_slope <= 1.f;
+    auto by_shuffle = [&](auto res_c, auto scale_c, auto res2_c) {
+      if (full) {
+        if (a.ps) run_full(res_c, scale_c, res2_c, T{}, F{});
+        else run_full(res_c, scale_c, res2_c, F{}, F{});
+      } else if (a.ps) {
+        run(res_c, scale_c, res2_c, T{});
+      } else {
+        run(res_c, scale_c, res2_c, F{});
+      }
+    };
+    if (!has_res) {
+      // (plane sums are requested only for launches made of whole tiles -- conv_plane_sum_slots on the host)
+      if constexpr (KS == 3 && S == 1 && BF == 0 && !HALF && DY == 1) {
+        if (a.plane_sums != nullptr && full && !a.ps) {
+          run_full(F{}, F{}, F{}, F{}, T{});
+          DVC_STAMP(3);
+          return;
+        }
+      }
+      by_shuffle(F{}, F{}, F{});
     }
+    else if (has_scale) { if (has_res2) by_shuffle(T{}, T{}, T{}); else by_shuffle(T{}, T{}, F{}); }
+    else { if (has_res2) by_shuffle(T{}, F{}, T{}); else by_shuffle(T{}, F{}, F{}); }
+    DVC_STAMP(3);
+    return;
+  }
+
+  // General path: one 4-byte store per accumulator register.
+  const int ox = ox0 + l32;
+  if (ox >= a.wo) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int cu0 = cb0 + mt * 32;   // wave-uniform first channel of the tile
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int oy = oy0 + wave * NT + nt;
+      if (oy >= a.ho) continue;
+      float rv[16], rv2[16];
+      if (!a.ps) {
+        const unsigned pix = (unsigned)(oy * a.wo + ox);
+        const unsigned o_lane = 4u * half * (unsigned)a.ocs + pix;
+        const unsigned r_lane = 4u * half * (unsigned)a.rcs + pix;
+        const unsigned r2_lane = 4u * half * (unsigned)a.r2cs + pix;
+        if (has_res) {   // issue all residual loads of the tile before using any
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cu = cu0 + (r & 3) + 8 * (r >> 2);
+            const bool ok = cu + 4 * half < a.cout;
+            // channels past Cout do not exist in the residual: such registers read channel 0, offset 0
+            const int cu_ld = cu < a.cout ? cu : 0;   // wave-uniform
+            rv[r] = (res_n + (long long)cu_ld * a.rcs)[ok ? r_lane : 0u];
+            if (has_scale) rv[r] = __fmul_rn(rv[r], a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)]);
+            rv2[r] = has_res2 ? (res2_n + (long long)cu_ld * a.r2cs)[ok ? r2_lane : 0u] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = cu0 + (r & 3) + 8 * (r >> 2);
+          if (cu + 4 * half >= a.cout) continue;
+          float v = acc[mt][nt][r] + bias_r[r];
+          v = dvc::leaky(v, a.out_slope);   // slope 1 when the layer has no output activation
+          if (has_res) {
+            v = __fadd_rn(v, rv[r]);
+            if (has_res2) v = __fadd_rn(v, rv2[r]);
+          }
+          (out_n + (long long)cu * a.ocs)[o_lane] = v;
+        }
+      } else {
+        // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); registers
+        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.  With
+        // co = cu + 4 half: shuffled channel (cu>>2) + half, row parity (cu>>1)&1.
+        const unsigned wo2 = 2u * (unsigned)a.wo;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int cu = cu0 + (r & 3) + 8 * (r >> 2);   // even
+          const bool ok = cu + 4 * half < a.cout;
+          const int c2u = cu >> 2, dy = (cu >> 1) & 1;
+          const unsigned pix = (unsigned)(2 * oy + dy) * wo2 + 2u * (unsigned)ox;
+          float v0 = acc[mt][nt][r] + bias_r[r], v1 = acc[mt][nt][r + 1] + bias_r[r + 1];
+          v0 = dvc::leaky(v0, a.out_slope);
+          v1 = dvc::leaky(v1, a.out_slope);
+          if (has_res && ok) {
+            const float2 t = *reinterpret_cast<const float2*>(res_n + (long long)c2u * a.rcs + (half * (unsigned)a.rcs + pix));
+            const float sc = has_scale ? a.res_scale[n * a.c_final + c2u + half] : 1.f;
+            v0 = __fadd_rn(v0, has_scale ? __fmul_rn(t.x, sc) : t.x);
+            v1 = __fadd_rn(v1, has_scale ? __fmul_rn(t.y, sc) : t.y);
+            if (has_res2) {
+              const float2 u = *reinterpret_cast<const float2*>(res2_n + (long long)c2u * a.r2cs + (half * (unsigned)a.r2cs + pix));
+              v0 += u.x;
+              v1 += u.y;
+            }
+          }
+          if (ok)
+            *reinterpret_cast<float2*>(out_n + (long long)c2u * a.ocs + (half * (unsigned)a.ocs + pix)) = make_float2(v0, v1);
+        }
+      }
+    }
+  }
+  };
+
+  if constexpr (G::WSP) {
+    // ---- wave-specialised K loop (see Geo::WSP): one barrier per chunk, taken by all eight waves.
+    // Persistent: the launch is one workgroup per CU, and workgroup b walks the work items (sample, channel block,
+    // tile; the tile fastest) first, first + stride, ... of the contiguous eighth of the launch that belongs to its
+    // XCD (workgroups go to the XCDs round-robin).  Chunks are numbered through the whole walk: chunk g lives in
+    // buffer pair g & 1, and while the multiplying waves are in the last chunk of a tile the staging waves are
+    // already bringing in the first chunk of the next -- a tile's fill is hidden behind its predecessor.  The
+    // epilogue's transposition tiles use the weight buffer of the chunk just finished; one more barrier per tile keeps
+    // the staging waves from refilling it (they are one chunk ahead and would otherwise reach it next).
+    constexpr int WSTEP = G::WSTEP, WCH = KS * WSTEP;   // a chunk's three tap-row slabs are contiguous in the packed image
+    static_assert(WCH % 512 == 0, "whole 1 KiB pieces per staging wave");
+    static_assert(WCH * 4 >= 4 * 32 * 36 * 4, "epilogue tiles inside one weight buffer");
+    using V8 = typename Half16<G::F16>::V8;
+    const int stride = (int)(gridDim.x >> 3);
+    const int first = (int)((long long)(blockIdx.x & 7) * a.total_items / 8) + (int)(blockIdx.x >> 3);
+    const int last = (int)((long long)((blockIdx.x & 7) + 1) * a.total_items / 8);
+    if (first >= last) return;   // (workgroup-uniform, before any barrier)
+    const int n_total = ((last - first + stride - 1) / stride) * nchunks;   // chunks of this workgroup's walk
+    auto enter = [&](int item) __attribute__((always_inline)) {
+      const int per_sample = a.tiles_xy * a.cblocks;
+      const int bz = item / per_sample, rem = item - bz * per_sample;
+      const int by = rem / a.tiles_xy;
+      set_tile(rem - by * a.tiles_xy, by, bz);
+    };
+    if (stager) {
+      // The four staging waves work as two pairs that swap roles every chunk interval.  In the interval in which
+      // the multiplying waves are in chunk v, the pair (v & 1) STREAMS: it requests the weight slabs of chunk v + 1
+      // (DMA into the buffer chunk v - 1 has left) and the input tile of chunk v + 2 (into registers: no buffer is
+      // free for it yet), and the other pair CONVERTS: it splits the input of chunk v + 1, which it requested one
+      // interval earlier, into its 16-bit parts and writes it to LDS.  A wave that requests memory spends the
+      // interval stalled at the request queue (a CU sustains about 10 bytes per cycle of such requests, whatever the
+      // request size or the number of CUs at work -- measured), so requests and conversion only overlap when they
+      // come from different waves; in lockstep they add up to more than the chunk's 216 MFMAs.
+      const int pair = wave >> 1, ptid = tid & 127;
+      constexpr int PT2 = (CHS + 127) / 128;       // tile elements per lane of a pair and channel
+      float rin2[CK][PT2];
+      unsigned boff2[PT2];
+      __amdgpu_buffer_rsrc_t wrsrc2;
+      const int per_sample = a.tiles_xy * a.cblocks;
+      // tile state of the input cursor (this pair's next chunk to request) and of the weight cursor
+      auto enter_input = [&](int item) __attribute__((always_inline)) {
+        const int bz = item / per_sample, rem = item - bz * per_sample;
+        const int t = rem % a.tiles_xy;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int gy0 = ty * TH - PAD, gx0 = tx * TW - PAD;
+#pragma unroll
+        for (int j = 0; j < PT2; ++j) {
+          const int i = ptid + 128 * j;
+          const int iy = i / IW, ix = i - iy * IW;
+          const int gy = gy0 + iy, gx = gx0 + ix;
+          const bool ok = (i < CHS) && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+          boff2[j] = ok ? 4u * (unsigned)(gy * a.w + gx) : 0x80000000u;
+        }
+        sp0 = a.src[0].ptr + (long long)bz * a.src[0].batch_stride;
+        sp1 = a.src[1].ptr + (long long)bz * a.src[1].batch_stride;
+        sp2 = a.src[2].ptr + (long long)bz * a.src[2].batch_stride;
+        sp3 = a.src[3].ptr + (long long)bz * a.src[3].batch_stride;
+      };
+      auto enter_weights = [&](int item) __attribute__((always_inline)) {
+        const int wb = (item % per_sample) / a.tiles_xy;
+        wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpacked + (long long)wb * nchunks * WCH), 0,
+                                                   (unsigned)(4u * (unsigned)nchunks * (unsigned)WCH), 0x00020000);
+      };
+      // a cursor over every second chunk of the walk: (item, chunk of the item)
+      auto advance = [&](int& item, int& c) __attribute__((always_inline)) -> bool {   // true: the item changed
+        c += 2;
+        bool moved = false;
+        while (c >= nchunks) { c -= nchunks; item += stride; moved = true; }
+        return moved;
+      };
+      auto issue_input = [&](const __amdgpu_buffer_rsrc_t rsrc, unsigned so, auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+#pragma unroll
+        for (int j = 0; j < PT2; ++j)
+          rin2[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, boff2[j], so, 0));
+      };
+      int in_item = first, in_c = pair - 2;      // chunks pair, pair + 2, ... of the walk
+      int w_item = first, w_c = (pair ^ 1) - 2;  // chunks pair ^ 1, ...
+      if (advance(in_item, in_c) || true) { if (in_item < last) enter_input(in_item); }
+      if (advance(w_item, w_c) || true) { if (w_item < last) enter_weights(w_item); }
+      int cv = 0;   // chunk of the tile the multiplying waves are in
+      for (int v = -2;; ++v) {
+        if ((v & 1) == pair) {
+          DVC_CSTAMP_T(cv == 2, 11, 256);   // (diagnostic build; four chunks per tile: wave 4 streams in chunks 0 and 2)
+          if (v >= -1 && w_item < last) {   // weight slabs of chunk v + 1: 1 KiB pieces, round-robin over the pair
+            float* dst = w_s + ((v + 1) & 1) * WCH;
+            const unsigned soff = 4u * (unsigned)w_c * (unsigned)WCH;
+#pragma unroll
+            for (int p = 0; p < WCH / 512; ++p) {   // WCH / 256 pieces, half of them per wave of the pair
+              const int piece = (wave & 1) + 2 * p;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc2, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16,
+                                                       16u * (unsigned)lane, soff + 1024u * (unsigned)piece, 0, 0);
+            }
+            if (advance(w_item, w_c) && w_item < last) enter_weights(w_item);
+          }
+          if (in_item < last) {             // input of chunk v + 2
+            const Fetch f = prefetch_begin_with(in_c * CK, issue_input);
+            if (f.fast) {
+              static_for<CK>([&](auto cc) __attribute__((always_inline)) {
+                const unsigned so = f.soff0 + (unsigned)decltype(cc)::value * f.cs4;
+                issue_input(channel_rsrc(f, so), so, cc);
+              });
+            }
+            __builtin_amdgcn_s_waitcnt(0xCF7F);   /* vmcnt(63): the input requests just made may stay in flight; the DMA pieces before them have landed */
+          } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) */
+          }
+          DVC_CSTAMP_T(cv == 2, 12, 256);
+        } else {
+          DVC_CSTAMP_T(cv == 1, 14, 256);
+          if (v >= -1 && in_item < last) {  // the input of chunk v + 1, requested one interval ago
+            V8* const d8 = reinterpret_cast<V8*>(in_s + ((v + 1) & 1) * IN_BUF) + ptid;
+#pragma unroll
+            for (int j = 0; j < PT2; ++j)
+              if (128 * (j + 1) <= CHS || ptid + 128 * j < CHS) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                  V8 hi, lo;
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) {
+                    float x = rin2[8 * o + e][j];
+                    if (in_act) x = dvc::leaky(x, in_slope);
+                    hi[e] = to_half16<G::F16>(x);
+                    lo[e] = to_half16<G::F16>(x - (float)hi[e]);
+                  }
+                  d8[o * CHS + 128 * j] = hi;
+                  d8[(2 + o) * CHS + 128 * j] = lo;   // [part][octet][element]
+                }
+              }
+            if (advance(in_item, in_c) && in_item < last) enter_input(in_item);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): the LDS writes have landed */
+          }
+          DVC_CSTAMP_T(cv == 1, 15, 256);
+        }
+        lds_barrier();
+        DVC_CSTAMP_T(cv == 1, 13, 256);
+        if (v >= 0) {
+          if (++cv == nchunks) {
+            cv = 0;
+            lds_barrier();   // the multiplying waves are done with the epilogue's LDS tiles
+            DVC_STAMP_NEXT_TILE();
+            if (v + 1 >= n_total) break;
+          }
+        }
+      }
+      return;
+    }
+    constexpr int APART = KS * 2 * CBP, BPART = 2 * CHS;   // second operand part, in 16-byte units
+    int g = 0;
+    lds_barrier();   // (the staging waves' two start-up intervals)
+    lds_barrier();
+    for (int item = first; item < last; item += stride) {
+      DVC_STAMP(0);
+      enter(item);
+      DVC_STAMP(1);
+      // (read by the epilogue, nchunks barriers from here; the previous tile's epilogue is behind the tile barrier)
+      if (tid < CB) bias_s[tid] = (a.bias != nullptr && cb0 + tid < a.cout) ? a.bias[cb0 + tid] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int c = 0; c < nchunks; ++c, ++g) {
+        const int cur = g & 1;
+        const V8* const bbase = reinterpret_cast<const V8*>(in_s + cur * IN_BUF) + b_lane8;
+        const V8* const wbase = reinterpret_cast<const V8*>(w_s + cur * WCH) + a_lane8;
+        DVC_CSTAMP(c == 1, 8);
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+          const V8* const abase = wbase + r * (WSTEP / 4);
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            V8 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              ah[mt] = abase[kx * 2 * CBP + mt * 32];
+              al[mt] = abase[APART + kx * 2 * CBP + mt * 32];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const V8 bh = bbase[(nt + r) * IW + kx];
+              const V8 bl = bbase[BPART + (nt + r) * IW + kx];
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {   // the small cross terms first, then the leading one
+                acc[mt][nt] = mfma16(al[mt], bh, acc[mt][nt]);
+                acc[mt][nt] = mfma16(ah[mt], bl, acc[mt][nt]);
+                acc[mt][nt] = mfma16(ah[mt], bh, acc[mt][nt]);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave is done reading the chunk's buffers */
+        DVC_CSTAMP(c == 1, 9);
+        lds_barrier();
+        DVC_CSTAMP(c == 1, 10);
+      }
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      epilogue(w_s + ((g - 1) & 1) * WCH, lane_e, lane_e >> 5, lane_e & 31);
+      __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): this wave's trips through the LDS tiles are over */
+      lds_barrier();
+      DVC_STAMP_NEXT_TILE();
+    }
+    return;
   } else if constexpr (G::STEPPED) {
     // ---- K loop in steps of (chunk, tap row); see Geo::STEPPED.  Per step: [last row of a chunk: convert the next
     // chunk's input (requested during row 0) into the other input buffer] -> request the slab NW-1 steps ahead ->
@@ -802,398 +1361,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
   }
   }   // (ordinary K loop)
 
-  DVC_STAMP(2);
-#ifdef DVC_EXP_NO_EPILOGUE   // experiment: how long the launch takes with no epilogue at all (wrong results)
-  if (a.h < 0) {
-    float sacc = 0.f;
-    for (int mt = 0; mt < MT; ++mt) for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
-    a.out[tid] = sacc;
-  }
-  return;
-#endif
-  // ---- epilogue: bias, activation, residual(s), (pixel-shuffle) store.
-  // Accumulator register r of tile mt holds output channel cb0 + 32 mt + (r&3) + 8 (r>>2) + 4 half.
-  // Addresses are formed as (wave-uniform channel base pointer) + (32-bit per-lane offset) so the
-  // 128 stores of a lane cost no 64-bit vector address arithmetic.
-  const bool has_res = a.res != nullptr, has_res2 = a.res2 != nullptr, has_scale = a.res_scale != nullptr;
-  float* const out_n = a.out + (long long)n * a.obs;
-  const float* const res_n = has_res ? a.res + (long long)n * a.rbs : nullptr;
-  const float* const res2_n = has_res2 ? a.res2 + (long long)n * a.r2bs : nullptr;
-
-  if constexpr (DY > 1) {
-    // Row pairs (launched only for sizes the tile divides, 16-byte aligned rows, no residual / shuffle): rows
-    // 0..15 of an accumulator tile are output row 2p, rows 16..31 output row 2p + 1 of channels 0..15.  The same
-    // trip through the wave's LDS tile as below; piece q of a lane = channel 8 (q & 1) + sub of row 2p + (q >> 1).
-    constexpr int RS = 36;
-    float* const tl = lds + wave * (32 * RS);
-    const int sub = lane >> 3, px4 = 4 * (lane & 7);
-    const unsigned o_lane = (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
-    const int lds_lane = sub * RS + px4;
-    const float out_slope = a.out_slope;
-    float4 cur[4];
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[4 * half + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int i = 0; i <= NT; ++i) {
-      if (i < NT) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 v = f32x2{acc[0][i][r], acc[0][i][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
-          const f32x2 sv = v * out_slope;
-          tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
-          tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
-        }
-      }
-      if (i > 0) {
-        const long long row0 = 2LL * (oy0 + wave * NT + (i - 1));
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(out_n + (long long)(8 * (q & 1)) * a.ocs + (row0 + (q >> 1)) * a.wo + ox0 + o_lane) = cur[q];
-      }
-      if (i < NT) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
-      }
-    }
-    DVC_STAMP(3);
-    return;
-  }
-  if (a.vec4) {
-    // Fast path (everything 16-byte aligned).  Store instructions, not bytes, are what the epilogue
-    // pays for, so each 32 channel x 32 pixel accumulator tile is turned through a wave-private LDS
-    // tile ([channel][pixel], row stride RS) and leaves as 16-byte stores: 4 per lane instead of 16.
-    // All waves are past the K loop's last barrier, so the staging buffers are free; a wave's LDS
-    // instructions execute in order, so its reads see its own writes without a barrier.
-    // The code is instantiated per residual configuration so that a tile is straight-line code: the
-    // residual loads of a tile are issued before its trip through LDS and are waited for only at the add.
-    constexpr int RS = 36;
-    static_assert(G::LDS_BYTES >= 4 * 32 * RS * 4, "epilogue tiles do not fit the staging buffers");
-    float* const tl = lds + wave * (32 * RS);
-    auto run = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c) {
-      constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
-      constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
-      // plain: 8 lanes x 16 B per channel row, quad q covers channels 8q + sub
-      // shuffle: conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)): an output
-      // row interleaves two adjacent conv channels; 16 lanes x 16 B per output row, a lane takes 2 pixels of
-      // both channels = 4 outputs; quad q covers output rows 4q + row of the tile (row = (channel, dy))
-      const int sub = lane >> 3, px4 = 4 * (lane & 7);
-      const int row = lane >> 4, px2 = 2 * (lane & 15);
-      const long long wo2 = 2LL * a.wo;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int cu0 = cb0 + mt * 32;
-        float bias_r[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int oy = oy0 + wave * NT + nt;
-          if (oy >= a.ho) continue;   // wave-uniform
-          // where the four 16-byte pieces of this lane go (stored-tensor channel, pixel offset)
-          bool ok[4];
-          int chs[4];
-          long long pix[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if constexpr (!PS) {
-              chs[q] = cu0 + 8 * q + sub;
-              ok[q] = chs[q] < a.cout && ox0 + px4 < a.wo;
-              pix[q] = (long long)oy * a.wo + ox0 + px4;
-            } else {
-              const int rr = 4 * q + row, c2l = rr >> 1, dy = rr & 1;
-              chs[q] = (cu0 >> 2) + c2l;
-              ok[q] = cu0 + 4 * c2l + 2 * dy < a.cout && ox0 + px2 < a.wo;
-              pix[q] = (2LL * oy + dy) * wo2 + 2 * (ox0 + px2);
-            }
-          }
-          float4 t[4], u[4];
-          float sc[4];
-          if constexpr (RES) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // lanes without a piece read the sample's first 16 bytes
-              t[q] = *reinterpret_cast<const float4*>(res_n + (ok[q] ? chs[q] * a.rcs + pix[q] : 0LL));
-              if constexpr (RES2) u[q] = *reinterpret_cast<const float4*>(res2_n + (ok[q] ? chs[q] * a.r2cs + pix[q] : 0LL));
-              if constexpr (SCALE) sc[q] = a.res_scale[n * a.c_final + (ok[q] ? chs[q] : 0)];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = dvc::leaky(acc[mt][nt][r] + bias_r[r], a.out_slope);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float4 v;
-            if constexpr (!PS) {
-              v = *reinterpret_cast<const float4*>(tl + (8 * q + sub) * RS + px4);
-            } else {
-              const int rr = 4 * q + row, chl = 4 * (rr >> 1) + 2 * (rr & 1);
-              const float2 e = *reinterpret_cast<const float2*>(tl + chl * RS + px2);
-              const float2 o = *reinterpret_cast<const float2*>(tl + (chl + 1) * RS + px2);
-              v = make_float4(e.x, o.x, e.y, o.y);
-            }
-            if constexpr (RES) {
-              if constexpr (SCALE) {
-                // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
-                v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, sc[q])); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, sc[q]));
-                v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, sc[q])); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, sc[q]));
-              } else {
-                v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
-              }
-              if constexpr (RES2) { v.x += u[q].x; v.y += u[q].y; v.z += u[q].z; v.w += u[q].w; }
-            }
-            if (ok[q]) *reinterpret_cast<float4*>(out_n + chs[q] * a.ocs + pix[q]) = v;
-          }
-#ifndef DVC_STAMP_CHUNKS
-          DVC_STAMP(8 + ((mt * NT + nt) & 7));
-#endif
-        }
-      }
-    };
-    // The common case -- no PixelShuffle, the whole 32*MT x TH x 32 tile inside the tensor -- as one
-    // branch-free software pipeline over the MT*NT accumulator tiles of the wave: tile i is written to the
-    // wave's LDS tile and read back transposed, and while those reads are in flight tile i-1 gets its
-    // residuals added and is stored (LDS executes a wave's accesses in order, so the single tile buffer
-    // needs no waits between tiles).  Addresses are a wave-uniform base per (tile, channel octet) plus one
-    // 32-bit per-lane offset computed once; the bias comes from LDS.
-    auto run_full = [&](auto res_c, auto scale_c, auto res2_c, auto ps_c, auto sums_c) {
-      constexpr bool RES = decltype(res_c)::value, SCALE = decltype(scale_c)::value;
-      constexpr bool RES2 = decltype(res2_c)::value, PS = decltype(ps_c)::value;
-      // SUMS: also emit, per output channel, the sum of the values this workgroup stores (the first stage of a
-      // deterministic two-stage plane sum: the squeeze-excite gate needs the plane means of this very tensor, and
-      // a separate pass would read all of it back from HBM)
-      constexpr bool SUMS = decltype(sums_c)::value;
-      static_assert(!SUMS || (!RES && !PS), "plane sums: plain stores without residual");
-      float psum[MT][4];
-      if constexpr (SUMS) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) psum[mt][q] = 0.f;
-      }
-      // plain: 8 lanes x 16 B per channel row; piece q of a lane = channel 8q + sub, pixels px4 .. px4+3.
-      // shuffle: conv channel co -> stored channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); 16 lanes x 16 B
-      // per stored row; piece q = stored channel 2q + (row>>1), row parity row&1, conv pixels px2, px2+1 of the
-      // two conv channels 8q + 4(row>>1) + 2(row&1) + {0, 1}.
-      const int sub = lane >> 3, px4 = 4 * (lane & 7);
-      const int row = lane >> 4, px2 = 2 * (lane & 15);
-      const long long wo2 = 2LL * a.wo;
-      const unsigned o_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.ocs + (unsigned)((row & 1) * wo2) + 2u * px2
-                                 : (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
-      const unsigned r_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.rcs + (unsigned)((row & 1) * wo2) + 2u * px2
-                                 : (unsigned)sub * (unsigned)a.rcs + (unsigned)px4;
-      const unsigned r2_lane = PS ? (unsigned)(row >> 1) * (unsigned)a.r2cs + (unsigned)((row & 1) * wo2) + 2u * px2
-                                  : (unsigned)sub * (unsigned)a.r2cs + (unsigned)px4;
-      const int lds_lane = PS ? (4 * (row >> 1) + 2 * (row & 1)) * RS + px2 : sub * RS + px4;
-      const int cq = PS ? 2 : 8;             // stored channels per piece index q
-      const int c0s = PS ? (cb0 >> 2) : cb0;   // first stored channel of the workgroup
-      const int cms = PS ? 8 : 32;           // stored channels per 32-channel accumulator group
-      const float out_slope = a.out_slope;
-      float4 cur[4], t[4];
-      float bias_r[16];
-      float sc[MT][4];
-      if constexpr (SCALE) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            sc[mt][q] = a.res_scale[n * a.c_final + c0s + mt * cms + cq * q + (PS ? (row >> 1) : sub)];
-      }
-      auto tile_pix = [&](int nt) -> long long {   // wave-uniform pixel offset of the tile inside a stored plane
-        const long long oy = oy0 + wave * NT + nt;
-        return PS ? 2 * oy * wo2 + 2LL * ox0 : oy * a.wo + ox0;
-      };
-      auto finish = [&](int mt, int nt) {   // residual adds + stores of a tile whose transposed values are in `cur`
-        const long long pix = tile_pix(nt);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float4 v = cur[q];
-          const long long ch = c0s + mt * cms + cq * q;   // wave-uniform stored channel of this piece (lane 0's)
-          if constexpr (RES) {
-            if constexpr (SCALE) {
-              // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
-              const float g = sc[mt][q];
-              v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, g)); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, g));
-              v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, g)); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, g));
-            } else {
-              v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
-            }
-            if constexpr (RES2) {   // (rare: loaded where it is used, to stay within the register budget)
-              const float4 u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix + r2_lane);
-              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-            }
-          }
-          *reinterpret_cast<float4*>(out_n + ch * a.ocs + pix + o_lane) = v;
-          if constexpr (SUMS) psum[mt][q] += (v.x + v.y) + (v.z + v.w);
-        }
-      };
-#pragma unroll
-      for (int i = 0; i <= MT * NT; ++i) {
-        if (i < MT * NT) {
-          const int mt = i / NT, nt = i - mt * NT;
-          if (nt == 0) {   // one batch of LDS reads per 32-channel group (not one dependent read per value)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {   // two values per instruction (v_pk_add_f32, v_pk_mul_f32)
-            const f32x2 v = f32x2{acc[mt][nt][r], acc[mt][nt][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
-            const f32x2 sv = v * out_slope;
-            // LeakyReLU / ReLU / identity (slope 1) as max(v, v * slope): equal to the select for 0 <= slope <= 1
-            tl[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.x, sv.x);
-            tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
-          }
-        }
-        if (i > 0) finish((i - 1) / NT, (i - 1) % NT);
-        if (i < MT * NT) {
-          const int mt = i / NT, nt = i - mt * NT;
-          // read tile i back transposed; consumed one iteration later, behind the next tile's arithmetic
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if constexpr (!PS) {
-              cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
-            } else {
-              const float2 e = *reinterpret_cast<const float2*>(tl + 8 * q * RS + lds_lane);
-              const float2 o = *reinterpret_cast<const float2*>(tl + (8 * q + 1) * RS + lds_lane);
-              cur[q] = make_float4(e.x, o.x, e.y, o.y);
-            }
-          }
-          if constexpr (RES) {   // this tile's residual operands, consumed one iteration later as well
-            const long long pix = tile_pix(nt);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              t[q] = *reinterpret_cast<const float4*>(res_n + (long long)(c0s + mt * cms + cq * q) * a.rcs + pix + r_lane);
-          }
-        }
-      }
-      if constexpr (SUMS) {
-        // a lane's psum[mt][q] covers 4 pixels x NT rows of channel 32 mt + 8 q + sub; the 8 lanes of a channel
-        // are adjacent: fold them, then the four waves through LDS, always in the same order
-        float* const red = lds + 4 * (32 * RS);   // [wave][CB], behind the transposition tiles
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float s = psum[mt][q];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            if ((lane & 7) == 0) red[wave * CB + mt * 32 + 8 * q + sub] = s;
-          }
-        __syncthreads();
-        if (tid < CB)
-          a.plane_sums[((long long)n * a.cout + cb0 + tid) * a.sum_slots + tile] =
-              (red[tid] + red[CB + tid]) + (red[2 * CB + tid] + red[3 * CB + tid]);
-      }
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    // (slopes outside [0, 1] never occur in the DMC graph; they take the general formulation below)
-    const bool full = cb0 + CB <= a.cout && ox0 + TW <= a.wo && oy0 + TH <= a.ho &&
-                      a.out_slope >= 0.f && a.out_slope <= 1.f;
-    auto by_shuffle = [&](auto res_c, auto scale_c, auto res2_c) {
-      if (full) {
-        if (a.ps) run_full(res_c, scale_c, res2_c, T{}, F{});
-        else run_full(res_c, scale_c, res2_c, F{}, F{});
-      } else if (a.ps) {
-        run(res_c, scale_c, res2_c, T{});
-      } else {
-        run(res_c, scale_c, res2_c, F{});
-      }
-    };
-    if (!has_res) {
-      // (plane sums are requested only for launches made of whole tiles -- conv_plane_sum_slots on the host)
-      if constexpr (KS == 3 && S == 1 && BF == 0 && !HALF && DY == 1) {
-        if (a.plane_sums != nullptr && full && !a.ps) {
-          run_full(F{}, F{}, F{}, F{}, T{});
-          DVC_STAMP(3);
-          return;
-        }
-      }
-      by_shuffle(F{}, F{}, F{});
-    }
-    else if (has_scale) { if (has_res2) by_shuffle(T{}, T{}, T{}); else by_shuffle(T{}, T{}, F{}); }
-    else { if (has_res2) by_shuffle(T{}, F{}, T{}); else by_shuffle(T{}, F{}, F{}); }
-    DVC_STAMP(3);
-    return;
-  }
-
-  // General path: one 4-byte store per accumulator register.
-  const int ox = ox0 + l32;
-  if (ox >= a.wo) return;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int cu0 = cb0 + mt * 32;   // wave-uniform first channel of the tile
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cu0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      bias_r[r] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int oy = oy0 + wave * NT + nt;
-      if (oy >= a.ho) continue;
-      float rv[16], rv2[16];
-      if (!a.ps) {
-        const unsigned pix = (unsigned)(oy * a.wo + ox);
-        const unsigned o_lane = 4u * half * (unsigned)a.ocs + pix;
-        const unsigned r_lane = 4u * half * (unsigned)a.rcs + pix;
-        const unsigned r2_lane = 4u * half * (unsigned)a.r2cs + pix;
-        if (has_res) {   // issue all residual loads of the tile before using any
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cu = cu0 + (r & 3) + 8 * (r >> 2);
-            const bool ok = cu + 4 * half < a.cout;
-            // channels past Cout do not exist in the residual: such registers read channel 0, offset 0
-            const int cu_ld = cu < a.cout ? cu : 0;   // wave-uniform
-            rv[r] = (res_n + (long long)cu_ld * a.rcs)[ok ? r_lane : 0u];
-            if (has_scale) rv[r] = __fmul_rn(rv[r], a.res_scale[n * a.c_final + (ok ? cu + 4 * half : 0)]);
-            rv2[r] = has_res2 ? (res2_n + (long long)cu_ld * a.r2cs)[ok ? r2_lane : 0u] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int cu = cu0 + (r & 3) + 8 * (r >> 2);
-          if (cu + 4 * half >= a.cout) continue;
-          float v = acc[mt][nt][r] + bias_r[r];
-          v = dvc::leaky(v, a.out_slope);   // slope 1 when the layer has no output activation
-          if (has_res) {
-            v = __fadd_rn(v, rv[r]);
-            if (has_res2) v = __fadd_rn(v, rv2[r]);
-          }
-          (out_n + (long long)cu * a.ocs)[o_lane] = v;
-        }
-      } else {
-        // conv channel co -> shuffled channel co>>2 at (2 oy + ((co>>1)&1), 2 ox + (co&1)); registers
-        // r, r+1 (r even) are the two horizontal neighbours, stored as one float2.  With
-        // co = cu + 4 half: shuffled channel (cu>>2) + half, row parity (cu>>1)&1.
-        const unsigned wo2 = 2u * (unsigned)a.wo;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int cu = cu0 + (r & 3) + 8 * (r >> 2);   // even
-          const bool ok = cu + 4 * half < a.cout;
-          const int c2u = cu >> 2, dy = (cu >> 1) & 1;
-          const unsigned pix = (unsigned)(2 * oy + dy) * wo2 + 2u * (unsigned)ox;
-          float v0 = acc[mt][nt][r] + bias_r[r], v1 = acc[mt][nt][r + 1] + bias_r[r + 1];
-          v0 = dvc::leaky(v0, a.out_slope);
-          v1 = dvc::leaky(v1, a.out_slope);
-          if (has_res && ok) {
-            const float2 t = *reinterpret_cast<const float2*>(res_n + (long long)c2u * a.rcs + (half * (unsigned)a.rcs + pix));
-            const float sc = has_scale ? a.res_scale[n * a.c_final + c2u + half] : 1.f;
-            v0 = __fadd_rn(v0, has_scale ? __fmul_rn(t.x, sc) : t.x);
-            v1 = __fadd_rn(v1, has_scale ? __fmul_rn(t.y, sc) : t.y);
-            if (has_res2) {
-              const float2 u = *reinterpret_cast<const float2*>(res2_n + (long long)c2u * a.r2cs + (half * (unsigned)a.r2cs + pix));
-              v0 += u.x;
-              v1 += u.y;
-            }
-          }
-          if (ok)
-            *reinterpret_cast<float2*>(out_n + (long long)c2u * a.ocs + (half * (unsigned)a.ocs + pix)) = make_float2(v0, v1);
-        }
-      }
-    }
-  }
+  epilogue(lds, lane, half, l32);
 }
 
 template <int KS, int S, int MT, int NT, bool HALF = false, int BF = 0, int DY = 1>
@@ -1219,6 +1387,23 @@ int launch(const ConvArgs& a, int batch, hipStream_t st) {
   b.tiles_x = (a.wo + G::TW - 1) / G::TW;
   b.sum_slots = b.tiles_x * tiles_y;
   dim3 grid(b.tiles_x * tiles_y, HALF ? 2 * ((a.cout + 63) / 64) : (a.cout + G::CB - 1) / G::CB, batch);
+  b.tiles_xy = (int)grid.x;
+  b.cblocks = (int)grid.y;
+  b.total_items = (int)(grid.x * grid.y * grid.z);
+  if constexpr (G::WSP) {
+    // persistent: one workgroup per CU (the 152 KB of LDS admit no second one), a multiple of the 8 XCDs
+    static std::atomic<int> cus{0};
+    int ncu = cus.load(std::memory_order_relaxed);
+    if (ncu == 0) {
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu < 8) ncu = 256;
+      cus.store(ncu, std::memory_order_relaxed);
+    }
+    int wgs = std::min(ncu & ~7, (b.total_items + 7) & ~7);
+#ifdef DVC_CONV_STAMPS
+    if (const char* f = getenv("DVC_CONV_WGS")) wgs = atoi(f);   // diagnostic build: fewer CUs at work
+#endif
+    grid = dim3(wgs, 1, 1);
+  }
   hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, S, MT, NT, HALF, BF, DY>), grid, dim3(G::THREADS), G::LDS_BYTES, st, b);
   return dvc::check_launch("conv_mfma_f32_kernel");
 }

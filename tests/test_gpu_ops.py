@@ -490,6 +490,48 @@ def test_conv2d_split_modes(k, stride, cins, cout, H, W, batch, in_slope, out_sl
     assert err < (2e-4 if mode == "bf16x2" else 1.5e-5), err
 
 
+# cins, cout, H, W, batch, n_res, shuffle -- sizes that select the 16-row, one-workgroup-per-CU form of the split modes
+PERSISTENT_CASES = [
+    ((64,), 64, 544, 960, 1, 2, False),      # two residuals
+    ((64,), 128, 544, 960, 2, 1, False),     # the walk crosses channel blocks and samples
+    ((128,), 256, 272, 480, 1, 1, True),     # PixelShuffle store with a residual, four channel blocks
+    ((64,), 64, 530, 962, 1, 1, False),      # ragged tiles on both edges, rows that are not whole 16-byte pieces
+    ((32, 40), 64, 536, 964, 1, 2, False),   # ragged tiles with 16-byte rows; ragged last chunk, chunk across two sources
+    ((16,), 64, 544, 960, 1, 0, False),      # a single chunk per tile
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16x2", "fp16x2"])
+@pytest.mark.parametrize("cins,cout,H,W,batch,n_res,shuffle", PERSISTENT_CASES)
+def test_conv2d_split_modes_persistent_form(cins, cout, H, W, batch, n_res, shuffle, mode):
+    """The 16-row form of the split modes keeps one workgroup per CU that walks many tiles, with staging waves that run
+    ahead of the multiplying waves across tile boundaries: every fused epilogue and edge case it can meet, against the
+    exact convolution (fp64) to the modes' accuracy -- ~2^-16 (bf16 parts) / ~2^-21 (fp16 parts) per product."""
+    from deepvideocodec_amd import ops
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(cout + H + n_res)
+    parts = [torch.randn(batch, c, H, W, generator=g) for c in cins]
+    cin = sum(cins)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    want = F.leaky_relu(F.conv2d(torch.cat(parts, 1).double(), w.double(), b.double(), padding=1), 0.1)
+    if shuffle:
+        want = F.pixel_shuffle(want, 2)
+    res = [torch.randn(want.shape, generator=g) for _ in range(n_res)]
+    for r in res:
+        want = want + r
+    got = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), out_slope=0.1, pixel_shuffle=shuffle,
+                     residual=dev(res[0]) if n_res >= 1 else None, residual2=dev(res[1]) if n_res == 2 else None,
+                     precision=ops.PRECISIONS[mode])
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err < (2e-4 if mode == "bf16x2" else 1.5e-5), err
+    # twice in a row into the same buffer: the walk leaves nothing behind
+    again = ops.conv2d([dev(p) for p in parts], dev(w), dev(b), out_slope=0.1, pixel_shuffle=shuffle,
+                       residual=dev(res[0]) if n_res >= 1 else None, residual2=dev(res[1]) if n_res == 2 else None,
+                       precision=ops.PRECISIONS[mode], out=torch.full_like(got, float("nan")))
+    assert torch.equal(again, got)
+
+
 def test_conv2d_fp16_split_range():
     """fp16 parts: operands far below the fp16 normal range keep an absolute accuracy of ~2^-25 (subnormal
     lo parts are not flushed), and operands beyond +-65504 saturate instead of becoming infinite."""

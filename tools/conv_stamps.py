@@ -65,14 +65,15 @@ def main():
           f"clock {np.median(cyc / np.maximum(dur, 1e-9)) / 1e3:.2f} GHz")
     tiles = st[:, 8:16].astype(np.float64) * 0.01 - t0
     if os.environ.get("DVC_STAMP_CHUNKS") == "wsp":
-        # wave-specialised kernel: slots 8..10 multiplying wave 0 (second chunk: start, MFMAs done, barrier passed),
-        # slots 11..13 staging wave 4 (same chunk: start staging the next chunk, staged and landed, barrier passed)
+        # wave-specialised kernel: slots 8..10 multiplying wave 0 (second chunk of a tile: start, MFMAs done, barrier
+        # passed); staging wave 4: slots 11, 12 its streaming interval (third chunk: start, requests issued and weight
+        # slabs landed), slots 14, 15, 13 its converting interval (second chunk: start, LDS writes landed, barrier passed)
         c = st[:, 8:16].astype(np.float64)
         for nm, sg in (("multiply: the chunk's 216 MFMAs", c[:, 1] - c[:, 0]), ("multiply: barrier wait", c[:, 2] - c[:, 1]),
-                       ("stage: whole", c[:, 4] - c[:, 3]), ("stage:   issue DMA + input requests", c[:, 6] - c[:, 3]),
-                       ("stage:   wait for the input, convert, commit", c[:, 7] - c[:, 6]), ("stage:   wait for the DMA", c[:, 4] - c[:, 7]),
-                       ("stage: barrier wait", c[:, 5] - c[:, 4])):
-            print(f"  {nm:40s} {sg.mean():9.0f} {np.median(sg):9.0f} {np.percentile(sg, 90):9.0f}  (shader cycles: mean / median / p90)")
+                       ("stage, streaming interval: requests issued, weights landed", c[:, 4] - c[:, 3]),
+                       ("stage, converting interval: convert + commit", c[:, 7] - c[:, 6]),
+                       ("stage, converting interval: barrier wait", c[:, 5] - c[:, 7])):
+            print(f"  {nm:62s} {sg.mean():9.0f} {np.median(sg):9.0f} {np.percentile(sg, 90):9.0f}  (shader cycles: mean / median / p90)")
     elif os.environ.get("DVC_STAMP_CHUNKS") == "stepped":
         # reduced-operand stepped K loop (library built with -DDVC_STAMP_CHUNKS): slots 8..15 are shader-clock stamps
         # of the second chunk: before / after the MFMAs of tap rows 0, 1, 2; after the last row's wait; after its barrier
