@@ -676,8 +676,13 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
       const int c0s = PS ? (cb0 >> 2) : cb0;   // first stored channel of the workgroup
       const int cms = PS ? 8 : 32;           // stored channels per 32-channel accumulator group
       const float out_slope = a.out_slope;
-      float4 cur[4], t[4];
-      float4 t2[(RES2 && G::WSP) ? 4 : 1];
+      // residual operands are requested D tiles ahead of their use.  (Looking two tiles ahead in the
+      // one-workgroup-per-CU form, which has no second workgroup to hide the wait behind, needs 16 more registers
+      // than its 256 hold -- it spilled; that form does request the second residual ahead, which the others load at
+      // its use)
+      constexpr int D = 1;
+      float4 cur[4], t[D][4];
+      float4 t2[(RES2 && G::WSP) ? D : 1][4];
       float bias_r[16];
       float sc[MT][4];
       if constexpr (SCALE) {
@@ -691,7 +696,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
         const long long oy = oy0 + wave * NT + nt;
         return PS ? 2 * oy * wo2 + 2LL * ox0 : oy * a.wo + ox0;
       };
-      auto finish = [&](int mt, int nt) {   // residual adds + stores of a tile whose transposed values are in `cur`
+      auto finish = [&](int mt, int nt, int slot) {   // residual adds + stores of a tile whose transposed values are in `cur`
         const long long pix = tile_pix(nt);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -701,16 +706,16 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             if constexpr (SCALE) {
               // product and sum rounded separately, like the unfused reference graph (x * gate, then +)
               const float g = sc[mt][q];
-              v.x = __fadd_rn(v.x, __fmul_rn(t[q].x, g)); v.y = __fadd_rn(v.y, __fmul_rn(t[q].y, g));
-              v.z = __fadd_rn(v.z, __fmul_rn(t[q].z, g)); v.w = __fadd_rn(v.w, __fmul_rn(t[q].w, g));
+              v.x = __fadd_rn(v.x, __fmul_rn(t[slot][q].x, g)); v.y = __fadd_rn(v.y, __fmul_rn(t[slot][q].y, g));
+              v.z = __fadd_rn(v.z, __fmul_rn(t[slot][q].z, g)); v.w = __fadd_rn(v.w, __fmul_rn(t[slot][q].w, g));
             } else {
-              v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w;
+              v.x += t[slot][q].x; v.y += t[slot][q].y; v.z += t[slot][q].z; v.w += t[slot][q].w;
             }
             if constexpr (RES2) {
               // (rare: loaded where it is used, to stay within the register budget -- except in the one-workgroup-per-CU
               // form, where no other workgroup hides the wait and the operand is requested a tile ahead like `t`)
               float4 u;
-              if constexpr (G::WSP) u = t2[q];
+              if constexpr (G::WSP) u = t2[slot][q];
               else u = *reinterpret_cast<const float4*>(res2_n + ch * a.r2cs + pix + r2_lane);
               v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
@@ -719,6 +724,20 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
           if constexpr (SUMS) psum[mt][q] += (v.x + v.y) + (v.z + v.w);
         }
       };
+      auto request_residuals = [&](int j) {   // tile j's residual operands into slot j % D
+        const int mt = j / NT, nt = j - mt * NT;
+        const long long pix = tile_pix(nt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          t[j % D][q] = *reinterpret_cast<const float4*>(res_n + (long long)(c0s + mt * cms + cq * q) * a.rcs + pix + r_lane);
+          if constexpr (RES2 && G::WSP)
+            t2[j % D][q] = *reinterpret_cast<const float4*>(res2_n + (long long)(c0s + mt * cms + cq * q) * a.r2cs + pix + r2_lane);
+        }
+      };
+      if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) request_residuals(j);
+      }
 #pragma unroll
       for (int i = 0; i <= MT * NT; ++i) {
         if (i < MT * NT) {
@@ -736,7 +755,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
           }
         }
-        if (i > 0) finish((i - 1) / NT, (i - 1) % NT);
+        if (i > 0) finish((i - 1) / NT, (i - 1) % NT, (i - 1) % D);
         if (i < MT * NT) {
           const int mt = i / NT, nt = i - mt * NT;
           // read tile i back transposed; consumed one iteration later, behind the next tile's arithmetic
@@ -750,15 +769,9 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
               cur[q] = make_float4(e.x, o.x, e.y, o.y);
             }
           }
-          if constexpr (RES) {   // this tile's residual operands, consumed one iteration later as well
-            const long long pix = tile_pix(nt);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              t[q] = *reinterpret_cast<const float4*>(res_n + (long long)(c0s + mt * cms + cq * q) * a.rcs + pix + r_lane);
-              if constexpr (RES2 && G::WSP)
-                t2[q] = *reinterpret_cast<const float4*>(res2_n + (long long)(c0s + mt * cms + cq * q) * a.r2cs + pix + r2_lane);
-            }
-          }
+        }
+        if constexpr (RES) {   // into the slot the tile just stored has left (D = 1: this tile's own, consumed one iteration later)
+          if (i + D - 1 < MT * NT) request_residuals(i + D - 1);
         }
       }
       if constexpr (SUMS) {
