@@ -518,13 +518,15 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     const unsigned o_lane = (unsigned)sub * (unsigned)a.ocs + (unsigned)px4;
     const int lds_lane = sub * RS + px4;
     const float out_slope = a.out_slope;
-    float4 cur[4];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 cur[4];
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = bias_s[4 * half + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-    for (int i = 0; i <= NT; ++i) {
-      if (i < NT) {
+    // (a constant-index loop: with a run-time index the four pieces end up in private memory)
+    static_for<NT + 1>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < NT) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const f32x2 v = f32x2{acc[0][i][r], acc[0][i][r + 1]} + f32x2{bias_r[r], bias_r[r + 1]};
@@ -533,17 +535,17 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
           tl[(((r + 1) & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = fmaxf(v.y, sv.y);
         }
       }
-      if (i > 0) {
+      if constexpr (i > 0) {
         const long long row0 = 2LL * (oy0 + wave * NT + (i - 1));
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(out_n + (long long)(8 * (q & 1)) * a.ocs + (row0 + (q >> 1)) * a.wo + ox0 + o_lane) = cur[q];
+          *reinterpret_cast<f32x4*>(out_n + (long long)(8 * (q & 1)) * a.ocs + (row0 + (q >> 1)) * a.wo + ox0 + o_lane) = cur[q];
       }
-      if (i < NT) {
+      if constexpr (i < NT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const float4*>(tl + 8 * q * RS + lds_lane);
+        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const f32x4*>(tl + 8 * q * RS + lds_lane);
       }
-    }
+    });
     DVC_STAMP(3);
     return;
   }
@@ -757,7 +759,6 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
         }
         if (i > 0) finish((i - 1) / NT, (i - 1) % NT, (i - 1) % D);
         if (i < MT * NT) {
-          const int mt = i / NT, nt = i - mt * NT;
           // read tile i back transposed; consumed one iteration later, behind the next tile's arithmetic
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
