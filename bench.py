@@ -60,6 +60,9 @@ def parse():
                     help="with --precision fp32: also time the same steps in these operand modes (comma-separated; 'none' "
                          "for no extra leg) and report them next to the headline with their deviation from the fp32 "
                          "results (never the headline value)")
+    ap.add_argument("--training-alt", default="fp16x2",
+                    help="with --training 1: also time the training steps with this operand mode in the forward and "
+                         "data-gradient convolutions ('none': fp32 leg only); reported as training.alt")
     ap.add_argument("--reuse", type=int, default=0,
                     help="1: encoder-side reuse (reconstruction from the encoder pass, no separate decode); "
                          "not the headline configuration")
@@ -330,16 +333,19 @@ def reduced_roofline(mode, probe):
     return out
 
 
-def training_leg(dev, world, rank, barrier, batch=32, size=256, frames=3, warmup=1, steps=3):
+def training_leg(dev, world, rank, barrier, batch=32, size=256, frames=3, warmup=1, steps=3, precision="fp32"):
     """One GPU's share of the reference's training workload (dmc/train.sh:3-9, dmc/train.py:285-346): batch 32 of
     T=3 random 256 x 256 crops, joint stage (epoch >= 40), lambda 2048, Adam 1e-4 / aux 1e-3, clip 1.0.  With more
-    than one rank the gradients are averaged by bucketed all-reduces before the optimizer steps."""
+    than one rank the gradients are averaged by bucketed all-reduces before the optimizer steps.  `precision`: operand
+    mode of the forward and data-gradient convolutions (weight gradients, everything else and all tensors stay fp32)."""
     from deepvideocodec_amd import train as TR
     from deepvideocodec_amd.models import DMC
     from deepvideocodec_amd.testing import seeded_state_dict, synthetic_gop
+    torch.manual_seed(1000 + rank)   # the quantisation noise of the training forward pass: the same draws in every leg
     net = DMC()
     net.load_state_dict(seeded_state_dict(seed=0))
     net = net.to(dev).train()
+    net.set_precision(precision, train=True)
     crit = TR.RateDistortionLoss(lmbda=2048.0)
     opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
     batches = [[f.to(dev) for f in synthetic_gop(frames, size, size, seed=rank * 100 + s, batch=batch)]
@@ -368,10 +374,14 @@ def training_leg(dev, world, rank, barrier, batch=32, size=256, frames=3, warmup
     return {"workload": f"train_step, batch {batch} per GPU x {world} GPU(s), T={frames}, {size}x{size} crops, joint stage, "
                         "lambda 2048, Adam + aux Adam, clip 1.0" + (", gradients all-reduced (RCCL)" if world > 1 else ""),
             "value": batch * world * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-            "warmup": warmup, "global_batch": batch * world, "dtype": "f32",
+            "warmup": warmup, "global_batch": batch * world,
+            "dtype": "f32" if precision == "fp32" else f"f32 tensors, accumulation and weight gradients; {precision} operands "
+                                                       "in the forward and data-gradient convolutions",
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                          "frac": tf / PEAK_FP32_MFMA_TFLOPS,
-                         "flops": "3 x forward algorithmic FLOPs (forward + data gradient + weight gradient)"},
+                         "flops": "3 x forward algorithmic FLOPs (forward + data gradient + weight gradient)"
+                                  + ("" if precision == "fp32" else "; priced against the fp32 matrix peak although two thirds "
+                                     "of them run on the 16-bit pipe: a comparison with the fp32 leg, not a utilisation")},
             "max_mem_gb": mem, "last_step": stats}
 
 
@@ -568,6 +578,12 @@ def main():
     training = None
     if args.training:
         training = training_leg(dev, world, rank, barrier)
+        if args.training_alt != "none":
+            # the same steps with split 16-bit operands in the forward / data-gradient convolutions: reported beside the
+            # fp32 number, never instead of it
+            training["alt"] = training_leg(dev, world, rank, barrier, precision=args.training_alt)
+            a, b = training["alt"]["last_step"], training["last_step"]
+            training["alt"]["d_loss_vs_fp32_rel"] = abs(a["loss"] - b["loss"]) / max(abs(b["loss"]), 1e-30)
 
     out = None
     if rank == 0:

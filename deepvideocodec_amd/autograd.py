@@ -29,11 +29,13 @@ class _Conv2d(torch.autograd.Function):
     LeakyReLU / ReLU / PixelShuffle / torch.cat of the reference graph)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, *srcs):
+    def forward(ctx, weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, precision,
+                dgrad_precision, *srcs):
         out = ops.conv2d(srcs, weight, bias, stride=stride, in_slope=in_slope, out_slope=out_slope,
-                         pixel_shuffle=pixel_shuffle, packed=packed)
+                         pixel_shuffle=pixel_shuffle, packed=packed, precision=precision)
         ctx.cfg = (stride, in_slope, out_slope, pixel_shuffle, bias is not None)
         ctx.dgrad_packed = dgrad_packed     # the layer's cached data-gradient weight image (or None: packed on demand)
+        ctx.dgrad_precision = dgrad_precision
         ctx.save_for_backward(weight, out if out_slope is not None else None, *srcs)
         return out
 
@@ -59,29 +61,40 @@ class _Conv2d(torch.autograd.Function):
         elif has_bias and need[1]:
             gb = ops.plane_dot(g_pre, None, sum_batch=True)
         gsrcs = [None] * len(srcs)
-        if any(need[8:]):
+        if any(need[10:]):
             # data gradient = stride-1 convolution of (zero-upsampled) g_pre with the flipped,
-            # transposed kernel -- the same MFMA kernel as the forward pass
+            # transposed kernel -- the same MFMA kernel as the forward pass (and in the same operand mode)
             gin = ops.zero_upsample2(g_pre, h, w) if stride == 2 else g_pre
-            image = ctx.dgrad_packed if ctx.dgrad_packed is not None else ops.pack_conv_weight_dgrad(weight.contiguous())
-            gx = ops.conv2d(gin, (cin, cout, k, k), None, stride=1, packed=image)
+            image = ctx.dgrad_packed if ctx.dgrad_packed is not None else dgrad_weight_image(weight, ctx.dgrad_precision)
+            gx = ops.conv2d(gin, (cin, cout, k, k), None, stride=1, packed=image, precision=ctx.dgrad_precision)
             c0 = 0
             for i, s in enumerate(srcs):
                 c1 = c0 + s.size(1)
-                if need[8 + i]:
+                if need[10 + i]:
                     gs = gx[:, c0:c1]
                     gsrcs[i] = ops.mul_act_grad(gs, s, in_slope) if in_slope is not None else gs
                 c0 = c1
-        return (gw, gb, None, None, None, None, None, None, *gsrcs)
+        return (gw, gb, None, None, None, None, None, None, None, None, *gsrcs)
+
+
+def dgrad_weight_image(weight: Tensor, precision: int = 0) -> Tensor:
+    """The kernel-layout image of the weight of `weight`'s data-gradient convolution (taps flipped, channel axes
+    swapped) in operand mode `precision`."""
+    if precision == 0:
+        return ops.pack_conv_weight_dgrad(weight.detach().contiguous())
+    return ops.pack_conv_weight(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), 1, precision=precision)
 
 
 def conv2d(srcs, weight, bias, stride=1, in_slope=None, out_slope=None, residual=None, res_scale=None,
-           residual2=None, pixel_shuffle=False, packed=None, dgrad_packed=None):
+           residual2=None, pixel_shuffle=False, packed=None, dgrad_packed=None, precision=0, dgrad_precision=0):
     """Differentiable ops.conv2d.  The residual adds are taken out of the convolution epilogue
-    (their adjoint needs the pre-residual activation) and run as add_scaled."""
+    (their adjoint needs the pre-residual activation) and run as add_scaled.  `precision` / `dgrad_precision`: operand
+    mode (ops.PRECISIONS) of the forward and of the data-gradient convolution -- `packed` / `dgrad_packed` must be images
+    in those modes; the weight gradient is always formed in fp32."""
     if isinstance(srcs, torch.Tensor):
         srcs = (srcs,)
-    y = _Conv2d.apply(weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, *srcs)
+    y = _Conv2d.apply(weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, precision,
+                      dgrad_precision, *srcs)
     if residual is not None:
         y = add_scaled(y, residual, res_scale, residual2)
     return y

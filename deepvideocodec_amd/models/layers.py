@@ -37,10 +37,18 @@ class Conv2d(nn.Module):
         self._packed = {}         # compute mode -> (key, kernel-layout image of `weight`)
         # inference-only option: 16-bit operand arithmetic, fp32 accumulation.  See DMC.set_precision().
         self.precision = 0      # ops.PRECISIONS: 0 exact fp32, 1 bf16, 2 bf16 hi + lo split, 3 fp16 hi + lo split
+        # the same for the forward and data-gradient convolutions under autograd (DMC.set_precision(..., train=True))
+        self.train_precision = 0
 
     def _precision(self) -> int:
         # layers with a handful of output channels (the flow and RGB heads) run on the vector ALUs in exact fp32
         return int(self.precision) if self.out_channels > 4 else 0
+
+    def _train_precisions(self):
+        """(forward, data-gradient) operand modes under autograd: the data gradient is a convolution with
+        `in_channels` outputs, so the rule about a handful of output channels applies to that count."""
+        p = int(self.train_precision)
+        return (p if self.out_channels > 4 else 0, p if self.in_channels > 4 else 0)
 
     def packed_weight(self, precision: int = 0) -> Tensor:
         """The slab-layout copy of the weight the kernel reads (one per compute mode), rebuilt when
@@ -53,15 +61,15 @@ class Conv2d(nn.Module):
             self._packed[precision] = hit
         return hit[1]
 
-    def dgrad_weight(self) -> Tensor:
+    def dgrad_weight(self, precision: int = 0) -> Tensor:
         """The kernel-layout image of the weight of this layer's data-gradient convolution (training): built once
-        per weight version, so the P frames of one step share it."""
+        per weight version and operand mode, so the P frames of one step share it."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
-        hit = self._packed.get("dgrad")
+        hit = self._packed.get(("dgrad", precision))
         if hit is None or hit[0] != key:
-            hit = (key, ops.pack_conv_weight_dgrad(w.detach().contiguous()))
-            self._packed["dgrad"] = hit
+            hit = (key, A.dgrad_weight_image(w, precision))
+            self._packed[("dgrad", precision)] = hit
         return hit[1]
 
     def forward(self, x: Srcs, in_slope=None, out_slope=None, residual=None, res_scale=None, residual2=None,
@@ -71,9 +79,11 @@ class Conv2d(nn.Module):
             # training path: same forward kernel, on the autograd tape (residual adds un-fused)
             if out is not None:
                 raise ValueError("Conv2d: `out=` is an inference-only option (call under torch.no_grad())")
+            pf, pd = self._train_precisions()
             return A.conv2d(x, self.weight, self.bias, stride=self.stride, in_slope=in_slope, out_slope=out_slope,
                             residual=residual, res_scale=res_scale, residual2=residual2,
-                            pixel_shuffle=pixel_shuffle, packed=self.packed_weight(), dgrad_packed=self.dgrad_weight())
+                            pixel_shuffle=pixel_shuffle, packed=self.packed_weight(pf), dgrad_packed=self.dgrad_weight(pd),
+                            precision=pf, dgrad_precision=pd)
         return ops.conv2d(x, self.weight.detach(), self.bias.detach(), stride=self.stride, in_slope=in_slope,
                           out_slope=out_slope, residual=residual, res_scale=res_scale, residual2=residual2,
                           pixel_shuffle=pixel_shuffle, out=out, packed=self.packed_weight(self._precision()),

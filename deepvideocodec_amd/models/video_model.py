@@ -652,19 +652,24 @@ class DMC(nn.Module):
             torch.cuda.synchronize()
         return self
 
-    def set_precision(self, precision: str = "fp32"):
+    def set_precision(self, precision: str = "fp32", train: bool = False):
         """"fp32" (default): exact fp32 convolutions, the parity path.  The other modes change how the
         convolutions form their products (fp32 accumulation and fp32 tensors throughout; layers with at most four
         output channels stay exact fp32; encoder and decoder must use the same setting):
         "bf16": operands rounded to bf16 (3-4x faster convolutions, visibly different results);
         "bf16x2": operands split into bf16 hi + lo parts (16 significant bits), three 16-bit matrix
         products per term; "fp16x2": the same with fp16 parts (22 significant bits; operands must stay
-        below ~1.3e5 in magnitude).  Inference only: under autograd the convolutions run in fp32."""
+        below ~1.3e5 in magnitude).  By default this concerns inference only and the convolutions under autograd stay
+        fp32; `train=True` sets the mode for those instead (forward and data-gradient convolutions; the weight
+        gradients are always formed in fp32) and leaves the inference setting alone."""
         if precision not in ops.PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}")
         for m in self.modules():
             if isinstance(m, Conv2d):
-                m.precision = ops.PRECISIONS[precision]
+                if train:
+                    m.train_precision = ops.PRECISIONS[precision]
+                else:
+                    m.precision = ops.PRECISIONS[precision]
         return self
 
     def aux_loss(self):

@@ -85,6 +85,85 @@ def test_conv2d_gradients(k, stride, cins, cout, H, W, batch, in_slope, out_slop
         close(a.grad, c.grad, what=f"grad src[{i}]")
 
 
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16x2"])
+@pytest.mark.parametrize("k,stride,cins,cout,H,W,batch,in_slope,out_slope,shuffle", [
+    (3, 1, (64,), 64, 64, 96, 8, None, 0.01, False),      # 16-row persistent form in both directions
+    (3, 1, (16, 8), 40, 17, 23, 1, 0.1, 0.01, False),
+    (3, 2, (67,), 64, 32, 48, 1, None, None, False),      # data gradient through the zero-upsampled stride-1 convolution
+    (7, 1, (32,), 64, 19, 70, 2, None, 0.0, False),
+    (1, 1, (64,), 32, 33, 47, 1, None, None, False),
+    (3, 1, (24,), 32, 10, 14, 2, None, 0.01, True),
+    (3, 1, (3,), 64, 20, 28, 1, None, None, False),       # three input channels: the data gradient stays exact fp32
+])
+def test_conv2d_gradients_split_operand_modes(k, stride, cins, cout, H, W, batch, in_slope, out_slope, shuffle, mode):
+    """Training with split 16-bit operands in the forward and data-gradient convolutions (DMC.set_precision(mode,
+    train=True)): outputs and gradients agree with torch.autograd in fp64 to the modes' accuracy; the weight and bias
+    gradients come from the fp32 kernels and see the mode only through the upstream gradient."""
+    from deepvideocodec_amd import autograd as A, ops
+    p = ops.PRECISIONS[mode]
+    g = torch.Generator().manual_seed(k * 31 + cout + H + stride)
+    cin = sum(cins)
+    parts = [torch.randn(batch, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    cp = [q.double().requires_grad_() for q in parts]
+    cw, cb = w.double().requires_grad_(), b.double().requires_grad_()
+    x = torch.cat(cp, 1)
+    pre = F.conv2d(F.leaky_relu(x, in_slope) if in_slope is not None else x, cw, cb, stride=stride, padding=k // 2)
+    y_ref = F.leaky_relu(pre, out_slope) if out_slope is not None else pre
+    # an output within the mode's rounding noise of the activation's kink gets either slope, legitimately: such
+    # elements (a few per million) receive no upstream gradient here
+    keep = (pre.detach().abs() > 1e-3).float()
+    if shuffle:
+        y_ref, keep = F.pixel_shuffle(y_ref, 2), F.pixel_shuffle(keep, 2)
+    R = torch.randn(y_ref.shape, generator=g) * keep
+    (y_ref * R.double()).sum().backward()
+
+    gp = [dev(q).requires_grad_() for q in parts]
+    gw, gb = dev(w).requires_grad_(), dev(b).requires_grad_()
+    pf, pd = (p if cout > 4 else 0), (p if cin > 4 else 0)
+    y = A.conv2d(gp, gw, gb, stride=stride, in_slope=in_slope, out_slope=out_slope, pixel_shuffle=shuffle,
+                 packed=ops.pack_conv_weight(dev(w), stride, precision=pf), dgrad_packed=A.dgrad_weight_image(dev(w), pd),
+                 precision=pf, dgrad_precision=pd)
+    rel = 3e-4 if mode == "bf16x2" else 2e-5
+    close(y, y_ref.detach().float(), rel=rel, what="forward")
+    (y * dev(R)).sum().backward()
+    close(gw.grad, cw.grad.float(), rel=rel, what="grad weight")
+    close(gb.grad, cb.grad.float(), rel=rel, what="grad bias")
+    for i, (a, c) in enumerate(zip(gp, cp)):
+        close(a.grad, c.grad.float(), rel=rel, what=f"grad src[{i}]")
+
+
+def test_training_step_in_split_operand_mode_tracks_fp32():
+    """One optimisation step of the whole model with fp16x2 operands in the forward / data-gradient convolutions: loss
+    terms and the updated weights stay within 1e-4 (relative) of the fp32 step."""
+    from deepvideocodec_amd import train as TR
+    from deepvideocodec_amd.models import DMC
+    from deepvideocodec_amd.testing import seeded_state_dict, synthetic_gop
+    results = {}
+    for mode in ("fp32", "fp16x2"):
+        torch.manual_seed(1234)   # the quantisation noise of the training forward pass: the same draw in both runs
+        net = DMC()
+        net.load_state_dict(seeded_state_dict(seed=0))
+        net = net.to("cuda:0").train().set_precision(mode, train=True)
+        crit = TR.RateDistortionLoss(lmbda=2048.0)
+        opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
+        frames = [f.to("cuda:0") for f in synthetic_gop(3, 128, 128, seed=5, batch=2)]
+        stats = TR.train_step(net, crit, frames, opt, aux_opt, 1.0, 45)
+        results[mode] = (stats, {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype == torch.float32})
+    a, b = results["fp16x2"], results["fp32"]
+    for key in ("loss", "mse_loss", "bpp_loss"):
+        assert abs(a[0][key] - b[0][key]) <= 1e-4 * abs(b[0][key]), (key, a[0][key], b[0][key])
+    # Adam's first step moves every weight by lr * sign(grad) (up to epsilon): compare where the gradient is not noise
+    worst = 0.0
+    for k in b[1]:
+        if "quantiles" in k or b[1][k].numel() == 0:   # (quantiles: stepped by the auxiliary optimiser at ten times the rate)
+            continue
+        d = (a[1][k] - b[1][k]).abs().max().item()
+        worst = max(worst, d)
+    assert worst <= 2.1e-4, worst   # at most one sign flip of a 1e-4 step on a gradient within rounding of zero
+
+
 def test_conv2d_wgrad_large_reduction():
     """A reduction long enough for many pixel slabs per block (256x256 crops, batch 4)."""
     from deepvideocodec_amd import autograd as A
