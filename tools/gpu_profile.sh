@@ -3,7 +3,7 @@
 #   1. kernel-trace stats of the default bench command and of the single-stream variant,
 #   2. separate counter passes (HBM fetch, HBM write) over the single-stream bench command,
 #   3. matrix-pipe counters over the dominant conv shapes,
-#   4. kernel-trace stats of one training configuration.
+#   4. kernel-trace stats of one training configuration, in fp32 and with fp16x2 operands.
 # Every GPU step has its own time limit and the script stops at the first failure.  The summaries are
 # written under gpurun_out/prof/ and copied to gpurun_out/profiles_TAG/ under the names profiles/ uses.
 set -e
@@ -58,6 +58,10 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 grep -h '^{' $O/train.log | tail -1 > $P/${TAG}_train_b32.json
 cp $O/train/train_kernel_stats.csv $P/${TAG}_train_b32_kernel_stats.csv
 echo "train done"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train16 -o train16 -- python3 tools/train_bench.py --batch 32 --frames 3 --size 256 --steps 3 --warmup 1 --precision fp16x2 > $O/train16.log 2>&1
+grep -h '^{' $O/train16.log | tail -1 > $P/${TAG}_train_b32_fp16x2.json
+cp $O/train16/train16_kernel_stats.csv $P/${TAG}_train_b32_fp16x2_kernel_stats.csv
+echo "train fp16x2 done"
 timeout -k 10 300 python3 tools/train_bench.py --batch 32 --frames 7 --size 256 --steps 2 --warmup 1 --recompute 1 > $O/train_t7.log 2>&1
 grep -h '^{' $O/train_t7.log | tail -1 > $P/${TAG}_train_b32_t7_recompute.json
 ls -la $P

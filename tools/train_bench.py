@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--epoch", type=int, default=45, help="selects the training stage (dmc/train.py:298-330)")
     ap.add_argument("--recompute", type=int, default=0, help="1: recompute the reconstruction / fusion blocks in backward")
+    ap.add_argument("--precision", default="fp32", help="operand mode of the forward / data-gradient convolutions "
+                                                        "(fp32, fp16x2, bf16x2, bf16); weight gradients stay fp32")
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks (one process per GPU); N > 1 without a launcher starts torch.distributed.run itself")
     args = ap.parse_args()
@@ -44,6 +46,7 @@ def main():
     net.load_state_dict(seeded_state_dict(seed=0))
     net = net.to(dev).train()
     net.recompute = bool(args.recompute)
+    net.set_precision(args.precision, train=True)
     crit = TR.RateDistortionLoss(lmbda=2048.0)
     opt, aux_opt = TR.configure_optimizers(net, 1e-4, 1e-3)
     batches = [[f.to(dev) for f in synthetic_gop(args.frames, args.size, args.size, seed=rank * 100 + s, batch=args.batch)]
@@ -80,7 +83,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "batch_per_gpu": args.batch,
             "recompute": bool(args.recompute),
             "approx_tflops_per_gpu": 3 * fwd_tflop / (el / args.steps), "last_step": stats,
-            "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "dtype": "f32", "data": "synthetic"}), flush=True)
+            "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (%s operands in the forward / data-gradient convolutions)" % args.precision,
+            "data": "synthetic"}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
