@@ -65,3 +65,6 @@ echo "train fp16x2 done"
 timeout -k 10 300 python3 tools/train_bench.py --batch 32 --frames 7 --size 256 --steps 2 --warmup 1 --recompute 1 > $O/train_t7.log 2>&1
 grep -h '^{' $O/train_t7.log | tail -1 > $P/${TAG}_train_b32_t7_recompute.json
 ls -la $P
+# the raw traces are large (gpurun copies back at most 64 MiB): keep the logs, drop the rest
+mkdir -p $P/logs && cp $O/*.log $P/logs/ 2>/dev/null || true
+rm -rf $O
