@@ -5,6 +5,7 @@
 // stores of a wave are contiguous 256-byte rows); channels are looped inside the
 // lane so the per-pixel coordinate math is done once for all channels.
 #include <atomic>
+#include <type_traits>
 
 #include "dvc_common.h"
 
@@ -58,12 +59,21 @@ __device__ __forceinline__ Bilin bilin_setup(int y, int x, float u, float v, int
 }
 
 // one expression for every kernel that interpolates, so that all of them round alike
+// (four products and three sums, each rounded: whether a product is fused into a sum must not depend on what
+// the optimiser finds around the call)
 __device__ __forceinline__ float bilin_mix(float vnw, float vne, float vsw, float vse, const Bilin& b) {
+#pragma clang fp contract(off)
   return vnw * b.nw + vne * b.ne + vsw * b.sw + vse * b.se;
 }
 
 __device__ __forceinline__ float bilin_fetch(const float* plane, const Bilin& b) {
   return bilin_mix(plane[b.o_nw], plane[b.o_ne], plane[b.o_sw], plane[b.o_se], b);
+}
+
+// The motion-estimation level input interpolates 3-channel images with the products fused into the sums where the
+// compiler does so (its results feed only that level's own convolutions; no other kernel has to reproduce them).
+__device__ __forceinline__ float bilin_fetch_fused(const float* plane, const Bilin& b) {
+  return plane[b.o_nw] * b.nw + plane[b.o_ne] * b.ne + plane[b.o_sw] * b.sw + plane[b.o_se] * b.se;
 }
 
 // (Measured and not kept: unrolling the channel loop, or a strip of rows per wave, leaves the time unchanged --
@@ -217,8 +227,198 @@ __global__ __launch_bounds__(256) void flow_warp_lds_kernel(Src src, Src flow, D
 #undef DVC_WARP_COMMIT
 }
 
+// The same warp with the two halves of the work on different waves.  In the kernel above one wave both requests
+// window rows and stores output rows, and the hardware counts a wave's loads and stores in ONE vector-memory
+// counter: every wait for a window also waits for the stores issued before it.  Here waves 4..7 only bring windows
+// into a ring of three LDS buffers (global -> LDS DMA, 16 bytes per lane, no register round trip; the window of
+// channel c + 2 is requested while channel c is interpolated) and wait for nothing but their own requests; waves
+// 0..3 only read LDS and store, and never wait for memory.  One bare barrier per channel, taken by all eight waves.
+// Same tile, same window, same arithmetic as above: bit-identical output.  Needs what the kernel above needs, and
+// channel offsets that fit the buffer instructions' 32-bit scalar offset.
+constexpr int WARP_RING = 3;
+
+// One LDS dword at (per-lane byte address + immediate).  Issues the read and returns: the value is valid only
+// behind an s_waitcnt lgkmcnt placed by the caller.
+template <int OFFSET_BYTES>
+__device__ __forceinline__ float warp_lds_read(unsigned addr) {
+  static_assert(OFFSET_BYTES >= 0 && OFFSET_BYTES < 65536, "DS instructions carry a 16-bit offset");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET_BYTES));
+  return v;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(512) void flow_warp_split_kernel(Src src, Src flow, Dst out, int h, int w, int tiles_x) {
+  constexpr int TH = 4 * RPL;
+  constexpr int SPT = (WARP_WIN_FLOATS / 4 + 255) / 256;   // 16-byte staging slots per loader lane
+  // (a buffer holds whole rounds of 256 pieces: slots past the window receive zeros instead of being skipped)
+  constexpr int BUF_FLOATS = SPT * 1024;
+  __shared__ __attribute__((aligned(16))) float win[WARP_RING][BUF_FLOATS];
+  __shared__ int red[4][4];
+  const int n = blockIdx.y;
+  const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x, (int)((blockIdx.y * gridDim.x) & 7));
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // wave-uniform
+  const int x = tx * 64 + lane, yb = ty * TH + wave * RPL;
+  const float* const sp = src.p + n * src.bs;
+  const float* const fpn = flow.p + n * flow.bs;
+  float* const opn = out.p + n * out.bs;
+
+  Bilin b[RPL];
+  bool ok[RPL];
+  if (!loader) {
+    int minx = 0x7fffffff, maxx = -1, miny = 0x7fffffff, maxy = -1;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int y = yb + r;
+      ok[r] = x < w && y < h;
+      const int pix = ok[r] ? y * w + x : 0;
+      b[r] = bilin_setup(ok[r] ? y : 0, ok[r] ? x : 0, fpn[pix], fpn[flow.cs + pix], h, w);
+      if (ok[r]) {
+        minx = min(minx, b[r].ix); maxx = max(maxx, b[r].ix1);
+        miny = min(miny, b[r].iy); maxy = max(maxy, b[r].iy1);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      minx = min(minx, __shfl_xor(minx, off, 64)); maxx = max(maxx, __shfl_xor(maxx, off, 64));
+      miny = min(miny, __shfl_xor(miny, off, 64)); maxy = max(maxy, __shfl_xor(maxy, off, 64));
+    }
+    if (lane == 0) { red[wave][0] = minx; red[wave][1] = maxx; red[wave][2] = miny; red[wave][3] = maxy; }
+  }
+  __syncthreads();
+  const int minx = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+  const int maxx = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+  const int miny = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+  const int maxy = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+  if (maxx < 0) return;
+  const int x0 = minx & ~3, y0 = miny;
+  const int wp = (maxx - x0 + 4) & ~3;
+  const int hh = maxy - y0 + 1;
+  const int nc = src.c;
+  if (wp * hh > WARP_WIN_FLOATS) {           // workgroup-uniform: the window does not fit, gather directly
+    if (loader) return;
+    for (int c = 0; c < nc; ++c) {
+      const float* const plane = sp + c * src.cs;
+      float* const op = opn + c * out.cs;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r)
+        if (ok[r]) op[(yb + r) * w + x] = bilin_fetch(plane, b[r]);
+    }
+    return;
+  }
+  // both roles pass exactly nc + 1 barriers from here on
+  if (loader) {
+    const int w4 = wp >> 2, nslots = w4 * hh;
+    unsigned voff[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+      const int idx = tid + 256 * s;
+      const int row = idx / w4, col = idx - row * w4;
+      const int gx = x0 + 4 * col;
+      const bool sok = idx < nslots && gx < w;
+      voff[s] = sok ? 4u * (unsigned)((y0 + row) * w + gx) : 0x80000000u;   // past the range: the slot receives zeros
+    }
+    const unsigned cs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)src.cs);
+    const unsigned plane_bytes = 4u * (unsigned)h * (unsigned)w;
+    auto request = [&](int c) __attribute__((always_inline)) {
+      float* const dst = win[c % WARP_RING] + 256 * wave;   // this wave's 64 pieces of every 256
+      // the channel is the scalar offset of the load; the range check compares the per-lane offset with
+      // (records - scalar offset), so the records end with this channel's plane
+      const unsigned soff = (unsigned)c * cs4;
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp), 0, soff + plane_bytes, 0x00020000);
+#pragma unroll
+      for (int s = 0; s < SPT; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + 1024 * s), 16,
+                                                 voff[s], soff, 0, 0);
+    };
+    constexpr int kVm0 = 0x0f70, kVmSPT = 0x0f70 | SPT;   // vmcnt(0) / vmcnt(SPT), nothing else waited for
+    request(0);
+    if (nc > 1) request(1);
+    if (nc > 1) __builtin_amdgcn_s_waitcnt(kVmSPT); else __builtin_amdgcn_s_waitcnt(kVm0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < nc; ++c) {
+      // buffer (c + 2) % 3 held channel c - 1: the interpolating waves left it before the barrier just passed
+      if (c + 2 < nc) {
+        request(c + 2);
+        __builtin_amdgcn_s_waitcnt(kVmSPT);    // channel c + 1 has landed
+      } else {
+        __builtin_amdgcn_s_waitcnt(kVm0);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // (ends the wave here, so that no path leads from the DMA requests to the other role's LDS reads: the
+    // compiler would otherwise make every one of those reads wait for all vector-memory traffic of its wave)
+    __builtin_amdgcn_endpgm();
+  }
+  int l_nw[RPL], l_ne[RPL], l_sw[RPL], l_se[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int rn = (b[r].iy - y0) * wp, rs = (b[r].iy1 - y0) * wp;
+    l_nw[r] = ok[r] ? rn + b[r].ix - x0 : 0; l_ne[r] = ok[r] ? rn + b[r].ix1 - x0 : 0;
+    l_sw[r] = ok[r] ? rs + b[r].ix - x0 : 0; l_se[r] = ok[r] ? rs + b[r].ix1 - x0 : 0;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // stores through a buffer descriptor: a pixel outside the image gets an offset past the range and is dropped,
+  // so the loop has no branches
+  unsigned ooff[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) ooff[r] = ok[r] ? 4u * (unsigned)((yb + r) * w + x) : 0x80000000u;
+  const unsigned ocs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)out.cs);
+  const unsigned oplane_bytes = 4u * (unsigned)h * (unsigned)w;
+  // LDS byte addresses of the four neighbours in ring buffer 0; the buffer of a channel is an immediate offset.
+  // The reads are explicit instructions the compiler does not see as LDS accesses: for a read it does see, it
+  // first waits until every store the wave has issued is complete (loads and stores share one counter here).
+  const unsigned win0 = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)&win[0][0];
+  unsigned a_nw[RPL], a_ne[RPL], a_sw[RPL], a_se[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    a_nw[r] = win0 + 4u * (unsigned)l_nw[r]; a_ne[r] = win0 + 4u * (unsigned)l_ne[r];
+    a_sw[r] = win0 + 4u * (unsigned)l_sw[r]; a_se[r] = win0 + 4u * (unsigned)l_se[r];
+  }
+  static_assert(RPL == 4, "the wait below names the sixteen values of four rows");
+  auto channel = [&](int c, auto slot) __attribute__((always_inline)) {
+    constexpr int OFF = decltype(slot)::value * BUF_FLOATS * 4;
+    float vnw[RPL], vne[RPL], vsw[RPL], vse[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      vnw[r] = warp_lds_read<OFF>(a_nw[r]); vne[r] = warp_lds_read<OFF>(a_ne[r]);
+      vsw[r] = warp_lds_read<OFF>(a_sw[r]); vse[r] = warp_lds_read<OFF>(a_se[r]);
+    }
+    // the values exist behind this wait; both statements name them as in-out so that no use can move above
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vnw[0]), "+v"(vne[0]), "+v"(vsw[0]), "+v"(vse[0]), "+v"(vnw[1]), "+v"(vne[1]), "+v"(vsw[1]),
+                   "+v"(vse[1]));
+    asm volatile(""
+                 : "+v"(vnw[2]), "+v"(vne[2]), "+v"(vsw[2]), "+v"(vse[2]), "+v"(vnw[3]), "+v"(vne[3]), "+v"(vsw[3]),
+                   "+v"(vse[3]));
+    const unsigned soff = (unsigned)c * ocs4;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(opn, 0, soff + oplane_bytes, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bilin_mix(vnw[r], vne[r], vsw[r], vse[r], b[r])),
+                                            orsrc, ooff[r], soff, 0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  static_assert(WARP_RING == 3 && 3 * BUF_FLOATS * 4 < 65536, "ring slots as immediate offsets of the reads");
+  for (int c = 0; c < nc; c += 3) {   // (nc is workgroup-uniform: every wave takes the same barriers)
+    channel(c, std::integral_constant<int, 0>{});
+    if (c + 1 < nc) channel(c + 1, std::integral_constant<int, 1>{});
+    if (c + 2 < nc) channel(c + 2, std::integral_constant<int, 2>{});
+  }
+}
+
 // Flat index over (n, c, oy, ox) of the output.
-#define DVC_FOREACH_OUT(total_expr)                                                     \
+#define DVC_FOREACH_OUT(total_expr)                                                    \
   const long long total_ = (total_expr);                                                \
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_; i += (long long)gridDim.x * 256)
 
@@ -304,7 +504,7 @@ __global__ __launch_bounds__(256) void spynet_level_input_kernel(Src im1, Src im
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       op[c * out.cs] = p1[c * im1.cs];
-      op[(3 + c) * out.cs] = bilin_fetch(p2 + c * im2.cs, b);
+      op[(3 + c) * out.cs] = bilin_fetch_fused(p2 + c * im2.cs, b);
     }
     op[6 * out.cs] = u;
     op[7 * out.cs] = v;
@@ -469,6 +669,12 @@ extern "C" int dvc_flow_warp(const DvcSrc* src, const DvcSrc* flow, const DvcDst
     // at 1088x1920: 460 -> 268 us, 4.0 TB/s of algorithmic bytes; at 272x480 the direct gather is the faster one)
     const int tiles_x = (w + 63) / 64;
     const long long tiles = (long long)tiles_x * ((h + 15) / 16);
+    if (tiles * batch >= 256 && tiles < (1LL << 31) && ((long long)src->channels + 1) * src->chan_stride * 4 < (1LL << 31) &&
+        ((long long)src->channels + 1) * out->chan_stride * 4 < (1LL << 31)) {
+      hipLaunchKernelGGL(flow_warp_split_kernel<4>, dim3((unsigned)tiles, batch), dim3(512), 0, (hipStream_t)stream,
+                         mk(src), mk(flow), mk(out), h, w, tiles_x);
+      return dvc::check_launch("flow_warp_split_kernel");
+    }
     if (tiles * batch >= 256 && tiles < (1LL << 31)) {
       hipLaunchKernelGGL(flow_warp_lds_kernel<4>, dim3((unsigned)tiles, batch), dim3(256), 0, (hipStream_t)stream,
                          mk(src), mk(flow), mk(out), h, w, tiles_x);

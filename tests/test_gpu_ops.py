@@ -184,7 +184,7 @@ def test_flow_warp_large_and_views():
 @pytest.mark.parametrize("h,w,batch", [(68, 120, 1), (100, 132, 16), (272, 480, 2), (544, 960, 1), (1088, 1920, 1)])
 def test_flow_warp_window_kernel_equals_direct_gather(h, w, batch):
     """Tensors with >= 16 channels and >= 256 tiles of 64 x 16 pixels (all cases here but the first) go through the
-    LDS-window kernel, thinner ones through the direct gather:
+    LDS-window kernel (loading and interpolating waves), thinner ones through the direct gather:
     the same planes warped 8 channels at a time must come out bit-identical, for motion that fits the window,
     motion that does not (tiles fall back inside the kernel), and positions clipped at every border."""
     from deepvideocodec_amd import ops
@@ -205,6 +205,13 @@ def test_flow_warp_window_kernel_equals_direct_gather(h, w, batch):
         want = torch.cat([ops.flow_warp(feat[:, c:c + 8].contiguous(), flow) for c in range(0, 40, 8)], 1)
         assert torch.equal(got, want), (name, float((got - want).abs().max()))
         close(got, O.flow_warp(feat.cpu(), flow.cpu()), rel=5e-5)
+        # channel counts that end the three-buffer ring at each of its slots, a source that is a channel slice of a
+        # wider tensor and a destination inside a wider tensor (channel strides larger than the plane)
+        for nch in (16, 17, 18):
+            wide = torch.full((batch, nch + 5, h, w), -7.0, device="cuda:0")
+            ops.flow_warp(feat[:, 3:3 + nch], flow, out=wide[:, 2:2 + nch])
+            assert torch.equal(wide[:, 2:2 + nch], want[:, 3:3 + nch]), (name, nch)
+            assert bool((wide[:, :2] == -7.0).all()) and bool((wide[:, 2 + nch:] == -7.0).all()), (name, nch)
 
 
 def test_pools_and_scaled_resampling():
