@@ -276,11 +276,22 @@ __device__ __forceinline__ float linspace_pm1(int idx, int steps) {
 // A workgroup takes an 8 x 32 tile of output pixels.  The sampling positions and the four bilinear
 // weights of a pixel are the same for every channel, and the flow is smooth: the 2 x 2 neighbourhoods
 // of a tile fall into a small window of the source plane.  When that window fits the LDS tile (it
-// does unless the flow varies by more than ~7 pixels inside the tile), the channels go through LDS
-// four at a time: the source window is loaded with coalesced reads, the gradient is scattered with LDS
-// atomics, and the window is flushed with one global atomic per touched element -- instead of four
-// scattered global atomics and four scattered loads per pixel and channel.  Tiles whose window does
-// not fit take those directly.
+// does unless the flow varies by more than ~50 pixels inside the tile), the channels go through LDS:
+// the source window is loaded with coalesced reads, the gradient is scattered with LDS atomics, and the
+// window is flushed with one global atomic per touched element -- instead of four scattered global
+// atomics and four scattered loads per pixel and channel.  The LDS holds sums and source values of four
+// channels of a window of up to 1280 elements (smooth motion), of two of up to 2560, of one of up to 5120, or
+// the sums alone of one channel of up to 10240 with the source values gathered from memory (a noisy motion
+// field, as the decoded motion of an untrained codec is: 84 % of the tiles of a 256 x 256 crop exceeded 1280
+// elements there, 43 % 5120, 3 % 10240, and the launch took 18.7 ms on scattered global atomics).  Tiles
+// whose window still does not fit take those directly.
+//
+// The LDS sums are 32-bit fixed point: a float add in LDS is carried out lane by lane (a wave's ds_add_f32
+// took ~160 cycles here, four per pixel and channel: 60 % of the kernel), an integer add is not.  Per tile
+// and channel the scale is the power of two that brings the largest |gradient| of the tile's 256 pixels to
+// [2^21, 2^22): an element collects at most one tap of each pixel, so a sum stays below 2^30, and a
+// contribution is rounded at 2^-22 of that maximum.  Integer sums do not depend on the order of arrival.  A
+// tile whose gradients are not all finite keeps float adds for that channel, so that NaN / Inf still propagate.
 struct WarpTap {
   int o_nw;            // offset of the north-west tap in the source plane
   bool in_e, in_s;     // east / south taps exist
@@ -321,8 +332,12 @@ constexpr int WB_TH = 8, WB_TW = 32, WB_CH = 4, WB_WIN = 1280;   // window eleme
 
 __global__ __launch_bounds__(256) void flow_warp_backward_kernel(Src src, Src flow, Src gout, Dst gsrc, int want_gsrc,
                                                                  Dst gflow, int want_gflow, int h, int w) {
-  __shared__ float s_src[WB_CH][WB_WIN];
-  __shared__ float s_acc[WB_CH][WB_WIN];
+  constexpr int WB_FLOATS = WB_CH * WB_WIN;
+  // [channel of the pass][window element] fixed-point sums (float bits for a channel whose gradients are not
+  // finite), then the source window of the same channels -- or, for a window of more than WB_FLOATS elements,
+  // one channel's sums alone (the source values are then gathered from memory)
+  __shared__ int s_buf[2 * WB_FLOATS];
+  __shared__ float s_max[WB_CH][4];    // per channel of the pass and wave: largest |gradient|
   __shared__ int s_box[4];   // min x, min y, max x, max y of the taps of the tile
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
@@ -347,46 +362,99 @@ __global__ __launch_bounds__(256) void flow_warp_backward_kernel(Src src, Src fl
   const int wsize = ww * wh;
   float gix = 0.f, giy = 0.f;
 
-  if (wsize <= WB_WIN) {   // workgroup-uniform
+  if (wsize <= 2 * WB_FLOATS) {   // workgroup-uniform
     const int l_nw = (t.iy - wy0) * ww + (t.ix - wx0);
-    for (int c0 = 0; c0 < gout.c; c0 += WB_CH) {
-      const int nch = min(WB_CH, gout.c - c0);
-      for (int idx = tid; idx < nch * wsize; idx += 256) {
-        const int k = idx / wsize, e = idx - k * wsize;
-        const int ey = e / ww, ex = e - ey * ww;
-        s_acc[k][e] = 0.f;
-        if (want_gflow) s_src[k][e] = src.p[n * src.bs + (c0 + k) * src.cs + (long long)(wy0 + ey) * w + wx0 + ex];
+    const bool stage_src = want_gflow && wsize <= WB_FLOATS;
+    const int cpp = wsize <= WB_FLOATS ? min(WB_CH, WB_FLOATS / wsize) : 1;   // channels per pass
+    int* const s_acc = s_buf;
+    float* const s_src = reinterpret_cast<float*>(s_buf + cpp * wsize);
+    // window elements tid, tid + 256, ... of a channel as (row, column), stepped without divisions
+    const int step_y = 256 / ww, step_x = 256 - step_y * ww;
+    const int ey0 = tid / ww, ex0 = tid - ey0 * ww;
+    const long long win_org = (long long)wy0 * w + wx0;
+    for (int c0 = 0; c0 < gout.c; c0 += cpp) {
+      const int nch = min(cpp, gout.c - c0);
+      float g[WB_CH];
+#pragma unroll
+      for (int k = 0; k < WB_CH; ++k) {
+        g[k] = (valid && k < nch) ? gout.p[n * gout.bs + (c0 + k) * gout.cs + pix] : 0.f;
+        float m = fabsf(g[k]);
+        if (!(m <= 3.0e38f)) m = __builtin_inff();   // NaN / Inf: marks the channel
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((tid & 63) == 0) s_max[k][tid >> 6] = m;
+      }
+      for (int k = 0; k < nch; ++k) {
+        const float* const sp = src.p + n * src.bs + (c0 + k) * src.cs + win_org;
+        int ey = ey0, ex = ex0;
+        for (int e = tid; e < wsize; e += 256) {
+          s_acc[k * wsize + e] = 0;
+          if (stage_src) s_src[k * wsize + e] = sp[ey * w + ex];
+          ex += step_x; ey += step_y;
+          if (ex >= ww) { ex -= ww; ++ey; }
+        }
       }
       __syncthreads();
-      if (valid) {
-        for (int k = 0; k < nch; ++k) {
-          const float g = gout.p[n * gout.bs + (c0 + k) * gout.cs + pix];
+      float unscale[WB_CH];   // 0: float sums
+#pragma unroll
+      for (int k = 0; k < WB_CH; ++k) {
+        const float m = fmaxf(fmaxf(s_max[k][0], s_max[k][1]), fmaxf(s_max[k][2], s_max[k][3]));
+        int ex2 = 0;
+        (void)frexpf(m, &ex2);                      // m = f 2^ex2, f in [0.5, 1)
+        ex2 = max(-100, ex2);                       // (a tile of vanishing gradients: keeps the scale finite)
+        unscale[k] = m <= 3.0e38f ? ldexpf(1.0f, ex2 - 22) : 0.f;
+        if (valid && k < nch) {
           if (want_gsrc) {
-            float* a = s_acc[k] + l_nw;
-            atomicAdd(a, g * (t.ss * t.ee));
-            if (t.in_e) atomicAdd(a + 1, g * (t.ss * t.we));
-            if (t.in_s) atomicAdd(a + ww, g * (t.ns * t.ee));
-            if (t.in_e && t.in_s) atomicAdd(a + ww + 1, g * (t.ns * t.we));
+            int* a = s_acc + k * wsize + l_nw;
+            const float c_nw = g[k] * (t.ss * t.ee), c_ne = g[k] * (t.ss * t.we);
+            const float c_sw = g[k] * (t.ns * t.ee), c_se = g[k] * (t.ns * t.we);
+            if (unscale[k] != 0.f) {
+              const float sc = ldexpf(1.0f, 22 - ex2);
+              atomicAdd(a, __float2int_rn(c_nw * sc));
+              if (t.in_e) atomicAdd(a + 1, __float2int_rn(c_ne * sc));
+              if (t.in_s) atomicAdd(a + ww, __float2int_rn(c_sw * sc));
+              if (t.in_e && t.in_s) atomicAdd(a + ww + 1, __float2int_rn(c_se * sc));
+            } else {
+              float* af = reinterpret_cast<float*>(a);
+              atomicAdd(af, c_nw);
+              if (t.in_e) atomicAdd(af + 1, c_ne);
+              if (t.in_s) atomicAdd(af + ww, c_sw);
+              if (t.in_e && t.in_s) atomicAdd(af + ww + 1, c_se);
+            }
           }
           if (want_gflow) {
-            const float* sp = s_src[k] + l_nw;
-            const float nw = sp[0];
-            const float ne = t.in_e ? sp[1] : 0.f;
-            const float sw = t.in_s ? sp[ww] : 0.f;
-            const float se = (t.in_e && t.in_s) ? sp[ww + 1] : 0.f;
-            gix += g * ((ne - nw) * t.ss + (se - sw) * t.ns);
-            giy += g * ((sw - nw) * t.ee + (se - ne) * t.we);
+            float nw, ne, sw, se;
+            if (stage_src) {   // workgroup-uniform
+              const float* sp = s_src + k * wsize + l_nw;
+              nw = sp[0];
+              ne = t.in_e ? sp[1] : 0.f;
+              sw = t.in_s ? sp[ww] : 0.f;
+              se = (t.in_e && t.in_s) ? sp[ww + 1] : 0.f;
+            } else {
+              const float* sp = src.p + n * src.bs + (c0 + k) * src.cs + t.o_nw;
+              nw = sp[0];
+              ne = t.in_e ? sp[1] : 0.f;
+              sw = t.in_s ? sp[w] : 0.f;
+              se = (t.in_e && t.in_s) ? sp[w + 1] : 0.f;
+            }
+            gix += g[k] * ((ne - nw) * t.ss + (se - sw) * t.ns);
+            giy += g[k] * ((sw - nw) * t.ee + (se - ne) * t.we);
           }
         }
       }
       __syncthreads();
       if (want_gsrc) {
-        for (int idx = tid; idx < nch * wsize; idx += 256) {
-          const int k = idx / wsize, e = idx - k * wsize;
-          const float v = s_acc[k][e];
-          if (v != 0.f) {
-            const int ey = e / ww, ex = e - ey * ww;
-            atomicAdd(gsrc.p + n * gsrc.bs + (c0 + k) * gsrc.cs + (long long)(wy0 + ey) * w + wx0 + ex, v);
+#pragma unroll
+        for (int k = 0; k < WB_CH; ++k) {
+          if (k >= nch) break;
+          float* const gp = gsrc.p + n * gsrc.bs + (c0 + k) * gsrc.cs + win_org;
+          const float us = unscale[k];
+          int ey = ey0, ex = ex0;
+          for (int e = tid; e < wsize; e += 256) {
+            const int q = s_acc[k * wsize + e];
+            if (q != 0) atomicAdd(gp + ey * w + ex, us != 0.f ? (float)q * us : __int_as_float(q));
+            ex += step_x; ey += step_y;
+            if (ex >= ww) { ex -= ww; ++ey; }
           }
         }
       }

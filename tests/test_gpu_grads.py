@@ -245,6 +245,27 @@ def test_warp_gradients_smooth_flow(channels, shift):
     close(dl.grad, cl.grad, rel=1e-3, what="grad flow")
 
 
+@pytest.mark.parametrize("sigma", [3.0, 6.0, 12.0, 30.0])
+def test_warp_gradients_noisy_flow(sigma):
+    """Noisy motion (the decoded motion of an untrained codec): the source window of an 8 x 32 tile grows with the
+    noise and the adjoint kernel takes fewer channels per pass through its LDS -- two (sigma 3), one (sigma 6), one
+    with the source values gathered from memory (sigma 12) -- or scatters directly (sigma 30); seven channels leave a
+    ragged last pass."""
+    from deepvideocodec_amd import autograd as A
+    g = torch.Generator().manual_seed(int(sigma))
+    feat = torch.randn(2, 7, 64, 96, generator=g)
+    flow = torch.randn(2, 2, 64, 96, generator=g) * sigma
+    cf, cl = feat.clone().requires_grad_(), flow.clone().requires_grad_()
+    y_ref = O.flow_warp(cf, cl)
+    R = torch.randn(y_ref.shape, generator=g)
+    (y_ref * R).sum().backward()
+    df, dl = dev(feat).requires_grad_(), dev(flow).requires_grad_()
+    y = A.flow_warp(df, dl)
+    (y * dev(R)).sum().backward()
+    close(df.grad, cf.grad, what="grad src")
+    close(dl.grad, cl.grad, rel=1e-3, what="grad flow")
+
+
 def test_pool_and_upsample_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(4)
