@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--precision", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16 hi+lo, 3 fp16 hi+lo (k 1/3 only)")
     ap.add_argument("--wgrad", type=int, default=0, help="1: time the weight-gradient kernel of the shape instead")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--residuals", type=int, default=0, help="residual operands added in the epilogue (0, 1 or 2; stride 1)")
     ap.add_argument("--custom", default="", help="extra shapes 'k,s,cin,cout,H,W;...' (run instead of --shapes)")
     args = ap.parse_args()
     names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
@@ -86,13 +87,18 @@ def main():
             total_f += flops
             continue
         packed = ops.pack_conv_weight(wt, s, precision=bf)
-        out = ops.conv2d(x, wt, b, stride=s, packed=packed, precision=bf)
+        res = {}
+        if args.residuals >= 1 and s == 1:
+            res["residual"] = torch.randn(args.batch, cout, h, w, device="cuda")
+        if args.residuals >= 2 and s == 1:
+            res["residual2"] = torch.randn(args.batch, cout, h, w, device="cuda")
+        out = ops.conv2d(x, wt, b, stride=s, packed=packed, precision=bf, **res)
         for _ in range(2):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf, **res)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf)
+            ops.conv2d(x, wt, b, stride=s, packed=packed, out=out, precision=bf, **res)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
