@@ -75,3 +75,24 @@ def test_built_fp32_convolution_objects_hold_their_waits():
                 assert problems == [], (os.path.basename(obj), problems[:5])
                 total += n
             assert total > 1000, (obj, total)   # the K loops' reads were seen at all
+
+
+def test_built_warp_object_holds_its_waits():
+    """flow_warp_split_kernel reads its LDS windows with explicit ds_read_b32 behind one hand-placed wait."""
+    obj = os.path.join(ROOT, "deepvideocodec_amd", "lib", "obj", "warp_resample.hip.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(chk.LLVM, "llvm-objdump")):
+        pytest.skip("no built object (make -C deepvideocodec_amd/csrc) or no llvm-objdump")
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        co = chk.extract_device_code(obj, tmp)
+        dis = subprocess.run([os.path.join(chk.LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True,
+                             check=True).stdout
+        seen = 0
+        for name, insns in chk.parse(dis).items():
+            n, problems = chk.check_function(name, insns)
+            assert problems == [], (name, problems[:5])
+            if "flow_warp_split_kernel" in name:
+                seen = n
+                assert not any(m.startswith("scratch_") for _, m, _, _ in insns), "private memory in the split warp kernel"
+        assert seen >= 48, seen   # three unrolled ring slots x sixteen reads
