@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void flow_warp_lds_kernel(Src src, Src flow, D
 // counter: every wait for a window also waits for the stores issued before it.  Here waves 4..7 only bring windows
 // into a ring of three LDS buffers (global -> LDS DMA, 16 bytes per lane, no register round trip; the window of
 // channel c + 2 is requested while channel c is interpolated) and wait for nothing but their own requests; waves
-// 0..3 only read LDS and store, and never wait for memory.  One bare barrier per channel, taken by all eight waves.
+// 0..3 only read LDS and store (per-lane addresses), and never wait for memory.  One bare barrier per channel, taken by all eight waves.
 // Same tile, same window, same arithmetic as above: bit-identical output.  Needs what the kernel above needs, and
 // channel offsets that fit the buffer instructions' 32-bit scalar offset.
 constexpr int WARP_RING = 3;
@@ -366,13 +366,6 @@ __global__ __launch_bounds__(512) void flow_warp_split_kernel(Src src, Src flow,
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  // stores through a buffer descriptor: a pixel outside the image gets an offset past the range and is dropped,
-  // so the loop has no branches
-  unsigned ooff[RPL];
-#pragma unroll
-  for (int r = 0; r < RPL; ++r) ooff[r] = ok[r] ? 4u * (unsigned)((yb + r) * w + x) : 0x80000000u;
-  const unsigned ocs4 = __builtin_amdgcn_readfirstlane(4u * (unsigned)out.cs);
-  const unsigned oplane_bytes = 4u * (unsigned)h * (unsigned)w;
   // LDS byte addresses of the four neighbours in ring buffer 0; the buffer of a channel is an immediate offset.
   // The reads are explicit instructions the compiler does not see as LDS accesses: for a read it does see, it
   // first waits until every store the wave has issued is complete (loads and stores share one counter here).
@@ -399,12 +392,17 @@ __global__ __launch_bounds__(512) void flow_warp_split_kernel(Src src, Src flow,
     asm volatile(""
                  : "+v"(vnw[2]), "+v"(vne[2]), "+v"(vsw[2]), "+v"(vse[2]), "+v"(vnw[3]), "+v"(vne[3]), "+v"(vsw[3]),
                    "+v"(vse[3]));
-    const unsigned soff = (unsigned)c * ocs4;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(opn, 0, soff + oplane_bytes, 0x00020000);
+    // (Plain predicated stores.  A branch-free form -- buffer stores with the channel as scalar offset and a
+    // descriptor whose size grows with it, a pixel outside the image dropped by the range check -- was bit-identical
+    // alone and wrong in lanes 48..63 of some waves in 40 % of the launches while another stream kept the GPU busy.
+    // Cause not established; what the two forms differ in is that the buffer store's scalar operands are rewritten
+    // for the next channel a few instructions after it is issued.)
+    float* const op = opn + c * out.cs;
 #pragma unroll
-    for (int r = 0; r < RPL; ++r)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bilin_mix(vnw[r], vne[r], vsw[r], vse[r], b[r])),
-                                            orsrc, ooff[r], soff, 0);
+    for (int r = 0; r < RPL; ++r) {
+      const float v = bilin_mix(vnw[r], vne[r], vsw[r], vse[r], b[r]);
+      if (ok[r]) op[(yb + r) * w + x] = v;
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

@@ -21,8 +21,11 @@ def _run(*extra):
 
 
 @pytest.mark.timeout(300)
-def test_flow_warp_repeats_identically_under_load():
-    out = _run("--precision", "fp32", "--warp-reps", "60")
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2"])
+def test_flow_warp_repeats_identically_under_load(precision):
+    """(the load thread's kernels differ with the operand mode: the persistent split-operand convolutions keep every
+    CU's memory queue full, which is what exposed a store form of the warp that was only correct alone)"""
+    out = _run("--precision", precision, "--warp-reps", "60")
     lines = [ln for ln in out.splitlines() if "repeats differ" in ln]
     assert len(lines) == 4, out[-2000:]
     for ln in lines:
