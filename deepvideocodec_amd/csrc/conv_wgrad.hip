@@ -471,6 +471,132 @@ __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
 }
 
 
+// ------------------------------------------------------------------ layers with <= 4 output channels
+// The last layer of every motion-estimation level (16 -> 2, 7x7) fills 2 of the 32 rows of a matrix-core block: the
+// 7x7 kernel above took 1.67 ms for it at 32 x 256 x 256 (3.9 TFLOP/s) where the layer's bytes need 0.05 ms; this
+// form takes 0.46-0.49 ms (bound by the round trips of staging a tile, two workgroups per CU).  Here the products run on the vector ALUs: thread (ci, ky)
+// keeps gW[co][ci][ky][0..KS) for every co in registers and walks the rows of a 4 x 32 pixel tile with a sliding
+// window of KS input values -- one LDS read of x, one 16-byte broadcast read of the gradients and KS x cout FMAs per
+// pixel.  2 or 4 groups of threads (Cin x KS <= 128 or <= 64) share the rows of a tile and count
+// as separate slabs of the pixel axis.  Workgroup `s` walks tiles s, s + S, ...; the partial sums go through the
+// same fixed-order reduction kernel as the other forms (layout [slab][tap][co][ci], no padding).
+template <int KS>
+struct WThin {
+  static constexpr int TH = 4, TW = 32, PAD = KS / 2, ROWS = TH + KS - 1, COLS = TW + KS - 1;
+  // LDS strides: rows KS banks apart and channels one bank apart, so that the threads (ci, ky) of a wave read
+  // different banks
+  static constexpr int RS = COLS + ((KS - COLS % 32) + 32) % 32;
+  static constexpr int CS = ROWS * RS + ((1 - (ROWS * RS) % 32) + 32) % 32;
+  static constexpr int MAX_CIN = 64;
+  static constexpr int lds_bytes(int cin) { return cin * CS * 4; }
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a, int parts) {
+  using T = WThin<KS>;
+  extern __shared__ float xs[];                      // [cin][ROWS][COLS] with strides CS, RS
+  __shared__ __attribute__((aligned(16))) float gs[T::TH * T::TW * 4];   // [pixel][co]
+  __shared__ const float* plane[T::MAX_CIN];         // channel -> plane of sample 0
+  __shared__ long long plane_bs[T::MAX_CIN];
+  const int tid = threadIdx.x;
+  const int slots = 256 / parts;
+  const int role = tid % slots, part = tid / slots;
+  const int nroles = a.cin * KS;
+  const bool active = role < nroles;
+  const int ci = active ? role / KS : 0, ky = active ? role - ci * KS : 0;
+  if (tid < a.cin) {
+    int c = tid, s = 0;
+    while (s + 1 < a.n_src && c >= a.src[s].channels) { c -= a.src[s].channels; ++s; }
+    plane[tid] = a.src[s].ptr + (long long)c * a.src[s].chan_stride;
+    plane_bs[tid] = a.src[s].batch_stride;
+  }
+  float acc[KS][4];
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+    for (int co = 0; co < 4; ++co) acc[kx][co] = 0.f;
+  const int tiles_per_sample = a.tiles_x * a.tiles_y;
+  const long long gplane = (long long)a.ho * a.wo;
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    const int n = t / tiles_per_sample, rem = t - n * tiles_per_sample;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int oy0 = ty * T::TH, ox0 = tx * T::TW;
+    __syncthreads();   // the previous tile has been consumed (first tile: the plane table is written)
+    float gv[2];   // the gradient tile: two values per thread, requested before the input tile and stored after it
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      const int co = idx / (T::TH * T::TW), px = idx - co * (T::TH * T::TW);
+      const int oy = oy0 + px / T::TW, ox = ox0 + px % T::TW;
+      gv[u] = (co < a.cout && oy < a.ho && ox < a.wo) ? a.g[((long long)n * a.cout + co) * gplane + (long long)oy * a.wo + ox] : 0.f;
+    }
+    // sixteen requests per thread in flight before the first is used (one at a time, the tile's ~50 dependent
+    // round trips to memory were 90 % of the kernel)
+    constexpr int U = 16;
+    const int total = a.cin * T::ROWS * T::COLS;
+    for (int base = tid; base < total; base += 256 * U) {
+      float v[U];
+      int la[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + 256 * u;
+        const int c = idx / (T::ROWS * T::COLS), r2 = idx - c * (T::ROWS * T::COLS);
+        const int ry = r2 / T::COLS, rx = r2 - ry * T::COLS;
+        const int iy = oy0 - T::PAD + ry, ix = ox0 - T::PAD + rx;
+        const bool inside = idx < total && iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+        la[u] = idx < total ? c * T::CS + ry * T::RS + rx : -1;
+        v[u] = inside ? plane[c][n * plane_bs[c] + (long long)iy * a.w + ix] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (la[u] >= 0) xs[la[u]] = dvc::leaky(v[u], a.in_slope);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      const int co = idx / (T::TH * T::TW), px = idx - co * (T::TH * T::TW);
+      gs[px * 4 + co] = gv[u];
+    }
+    __syncthreads();
+    if (active) {
+      for (int r = part; r < T::TH; r += parts) {
+        const float* const xr = xs + ci * T::CS + (r + ky) * T::RS;
+        const float4* const gr = reinterpret_cast<const float4*>(gs) + r * T::TW;
+        float win[KS];
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k) win[k] = xr[k];
+#pragma unroll
+        for (int ox = 0; ox < T::TW; ++ox) {
+          win[(ox + KS - 1) % KS] = xr[ox + KS - 1];
+          const float4 g4 = gr[ox];
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const float xv = win[(ox + kx) % KS];
+            acc[kx][0] += g4.x * xv; acc[kx][1] += g4.y * xv; acc[kx][2] += g4.z * xv; acc[kx][3] += g4.w * xv;
+          }
+          if (role == 0) { gsum[0] += g4.x; gsum[1] += g4.y; gsum[2] += g4.z; gsum[3] += g4.w; }
+        }
+      }
+    }
+  }
+  const long long slab = (long long)blockIdx.x * parts + part;
+  if (active) {
+    float* const pb = a.partial + slab * (KS * KS) * a.cout_pad * a.cin_pad;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < a.cout) pb[((long long)(ky * KS + kx) * a.cout_pad + co) * a.cin_pad + ci] = acc[kx][co];
+    if (role == 0 && a.bias_partial != nullptr) {
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < a.cout) a.bias_partial[slab * a.cout_pad + co] = gsum[co];
+    }
+  }
+}
+
+
 // gW[co][ci][tap] = sum over splits of partial[split][tap][co][ci]; gB[co] = sum over splits of
 // bias_partial[split][co] (indices past the weight's).  A block handles 64 results; its four waves each
 // add every fourth split (independent loads in flight instead of one long dependent chain) and the four
@@ -515,6 +641,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 
 struct Plan {
   int ho, wo, th, tiles_x, tiles_y, n_tiles, cout_pad, cin_pad, n_cib, blocks, nsplit, taps, mt, ct;
+  int thin_parts;   // > 0: the vector-ALU kernel for <= 4 output channels, with this many thread groups per tile
 };
 
 int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Plan* p, const char* who) {
@@ -532,6 +659,25 @@ int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Pl
   const long long nt = (long long)batch * p->tiles_x * p->tiles_y;
   DVC_REQUIRE(nt < (1LL << 30), "%s: too many tiles", who);
   p->n_tiles = (int)nt;
+  p->thin_parts = 0;
+  // (Cin x KS <= 128: at least two thread groups per tile.  With 64 input channels -- the 64 -> 3 reconstruction layer --
+  // the matrix-core form is as fast, 650 against 680 us at 32 x 256 x 256, although it pads 3 channels to 32)
+  if (cout <= 4 && stride == 1 && ks != 1 && cin * ks <= 128) {
+    const int roles = cin * ks;
+    p->thin_parts = roles <= 64 ? 4 : 2;
+    p->mt = p->ct = 1;
+    p->cout_pad = cout;
+    p->cin_pad = cin;
+    p->n_cib = 1;
+    p->blocks = 1;
+    p->taps = ks * ks;
+    // two workgroups per CU (more of them hide the staging round trips better, but every workgroup is a slab of
+    // partial sums for the reduction kernel, which has only Cout x Cin x taps / 64 workgroups to add them up with:
+    // 5 per CU measured 535 us against 455 us for 16 -> 2 7x7 at 32 x 256 x 256)
+    const int wgs = p->n_tiles < 512 ? p->n_tiles : 512;
+    p->nsplit = wgs * p->thin_parts;
+    return DVC_OK;
+  }
   p->mt = (cout > 32 && ks != 7) ? 2 : 1;   // 7x7: 32 x 32 blocks, one tap row per wave
   p->ct = (cin > 32 && ks != 7) ? 2 : 1;
   const int cob = 32 * p->mt, cib = 32 * p->ct;
@@ -589,6 +735,16 @@ int launch7(const WgradArgs& a, const Plan& p, hipStream_t st) {
   return dvc::check_launch("conv_wgrad7_kernel");
 }
 
+template <int KS>
+int launch_thin(const WgradArgs& a, const Plan& p, hipStream_t st) {
+  // (make_plan admits Cin * KS <= 128)
+  constexpr int kMaxCin = 128 / KS;
+  static_assert(WThin<KS>::lds_bytes(kMaxCin) + 4 * 4 * 32 * 4 + 64 * 16 <= 64 * 1024, "inside the default LDS limit");
+  hipLaunchKernelGGL(conv_wgrad_thin_kernel<KS>, dim3(p.nsplit / p.thin_parts), dim3(256), WThin<KS>::lds_bytes(a.cin), st, a,
+                     p.thin_parts);
+  return dvc::check_launch("conv_wgrad_thin_kernel");
+}
+
 template <int KS, int S>
 int launch_block(const WgradArgs& a, const Plan& p, hipStream_t st) {
   if (p.mt == 2) return p.ct == 2 ? launch<KS, S, 2, 2>(a, p, st) : launch<KS, S, 2, 1>(a, p, st);
@@ -644,7 +800,8 @@ extern "C" int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch
   a.in_slope = in_act ? in_slope : 1.0f;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
-  if (ksize == 3) rc = stride == 1 ? launch_block<3, 1>(a, p, st) : launch_block<3, 2>(a, p, st);
+  if (p.thin_parts > 0) rc = ksize == 3 ? launch_thin<3>(a, p, st) : launch_thin<7>(a, p, st);
+  else if (ksize == 3) rc = stride == 1 ? launch_block<3, 1>(a, p, st) : launch_block<3, 2>(a, p, st);
   else if (ksize == 1) rc = stride == 1 ? launch_block<1, 1>(a, p, st) : launch_block<1, 2>(a, p, st);
   else rc = launch7(a, p, st);
   if (rc) return rc;

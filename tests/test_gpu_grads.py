@@ -183,6 +183,34 @@ def test_conv2d_wgrad_large_reduction():
     close(gx.grad, cx.grad, what="grad x")
 
 
+@pytest.mark.parametrize("k,cin,cout,n,h,w,slope", [
+    (7, 16, 2, 3, 64, 96, None),      # the last layer of a motion-estimation level: two thread groups per tile
+    (3, 40, 3, 2, 45, 83, 0.01),      # ragged tiles, activation on the input
+    (3, 8, 4, 2, 33, 40, None),       # four thread groups per tile
+    (7, 18, 1, 1, 20, 70, 0.0),       # the widest 7x7 input the form takes
+    (3, 64, 3, 2, 45, 83, 0.01),      # the reconstruction layer: past the form's limit, on the matrix cores
+])
+def test_conv2d_wgrad_thin_layers(k, cin, cout, n, h, w, slope):
+    """Layers with <= 4 output channels and Cin x k <= 128 take the vector-ALU weight-gradient kernel: against torch
+    autograd, with the input split over two concatenated sources."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).requires_grad_()
+    b = torch.zeros(cout, requires_grad=True)
+    xa = x if slope is None else F.leaky_relu(x, slope)
+    y = F.conv2d(xa, wt, b, padding=k // 2)
+    R = torch.randn(y.shape, generator=g)
+    (y * R).sum().backward()
+    cut = cin // 3 + 1
+    srcs = (dev(x[:, :cut].contiguous()), dev(x[:, cut:].contiguous()))
+    gw, gb = ops.conv2d_wgrad(srcs, dev(R), wt.shape, 1, in_slope=slope, with_bias=True)
+    close(gw, wt.grad, rel=5e-5, what="grad weight")
+    close(gb, b.grad, rel=5e-5, what="grad bias")
+    gw1, _ = ops.conv2d_wgrad(dev(x), dev(R), wt.shape, 1, in_slope=slope, with_bias=True)
+    assert torch.equal(gw1, gw)       # one source or two: the same sums in the same order
+
+
 def test_residual_and_gate_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(11)
