@@ -318,6 +318,11 @@ struct W7 {
   static constexpr int LDS_BYTES = (32 * XSTR + 32 * GSTR) * 4;
 };
 
+// NARROW (Cin <= 8: the first layer of a motion-estimation level, 8 -> 32): the 32 columns of a matrix-core block are
+// 8 input channels x 4 horizontally adjacent taps instead of 32 channels at one tap -- column 8 j + ci reads the
+// staged tile j pixels to the right -- so a tap row takes 2 accumulator tiles (kx = 0..3, 4..6 and one idle
+// column group) instead of 7 with three quarters of every block multiplying zeros.
+template <bool NARROW>
 __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
   constexpr int TH = W7::TH, IW = W7::IW, XE = W7::XE, XSTR = W7::XSTR, XSLOTS = W7::XSLOTS;
   constexpr int GSTR = W7::GSTR, GSLOTS = W7::GSLOTS, CPW = W7::CPW;
@@ -408,14 +413,17 @@ __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
     }
   };
 
-  f32x16 acc[7];
+  constexpr int NACC = NARROW ? 2 : 7, KSTEP = NARROW ? 4 : 1;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 7; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const float* const a_base = g_s + l32 * GSTR + half;
-  const float* const b_base = x_s + l32 * XSTR + half + wave * IW;   // tap row ky = wave
+  // tap row ky = wave; NARROW: column l32 = input channel l32 & 7 at horizontal tap offset l32 >> 3
+  const float* const b_base = NARROW ? x_s + (l32 & 7) * XSTR + half + wave * IW + (l32 >> 3)
+                                     : x_s + l32 * XSTR + half + wave * IW;
 
   int t = blockIdx.x;
   prefetch_setup(t);
@@ -432,8 +440,8 @@ __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
         for (int px = 0; px < 32; px += 2) {
           const float av = a_base[row * 32 + px];
 #pragma unroll
-          for (int kx = 0; kx < 7; ++kx)
-            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_base[row * IW + px + kx], acc[kx], 0, 0, 0);
+          for (int kx = 0; kx < NACC; ++kx)
+            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_base[row * IW + px + kx * KSTEP], acc[kx], 0, 0, 0);
           if (px % 16 == 0) prefetch_piece(row * 2 + px / 16);   // 2 pieces per row: 8 = 2 CPW in all
           WG_SCHED_FENCE();
         }
@@ -458,13 +466,29 @@ __global__ __launch_bounds__(512) void conv_wgrad7_kernel(const WgradArgs a) {
   }
   if (wave < 7) {
     float* const pbase = a.partial + (long long)blockIdx.x * 49 * a.cout_pad * a.cin_pad;
+    if constexpr (NARROW) {
+      // (channels 8..31 of the padded block are never read back: the reduction stops at Cin)
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) {
-      float* const pt = pbase + (long long)(wave * 7 + kx) * a.cout_pad * a.cin_pad + ci0 + l32;
+      for (int grp = 0; grp < 2; ++grp) {
+        const int kx = 4 * grp + (l32 >> 3);
+        if (kx < 7) {
+          float* const pt = pbase + (long long)(wave * 7 + kx) * a.cout_pad * a.cin_pad + ci0 + (l32 & 7);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        pt[(long long)co * a.cin_pad] = acc[kx][r];
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            pt[(long long)co * a.cin_pad] = acc[grp][r];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        float* const pt = pbase + (long long)(wave * 7 + kx) * a.cout_pad * a.cin_pad + ci0 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          pt[(long long)co * a.cin_pad] = acc[kx][r];
+        }
       }
     }
   }
@@ -717,13 +741,14 @@ int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
   return dvc::check_launch("conv_wgrad_kernel");
 }
 
+template <bool NARROW>
 int launch7(const WgradArgs& a, const Plan& p, hipStream_t st) {
   static std::atomic<unsigned long long> attr_done{0};
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
   const unsigned long long device_bit = 1ull << device;
   if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad7_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad7_kernel<NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, W7::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(wgrad 7x7): %s", hipGetErrorString(e));
@@ -731,7 +756,7 @@ int launch7(const WgradArgs& a, const Plan& p, hipStream_t st) {
     }
     attr_done.fetch_or(device_bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(conv_wgrad7_kernel, dim3(p.nsplit, p.blocks, 1), dim3(512), W7::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(conv_wgrad7_kernel<NARROW>, dim3(p.nsplit, p.blocks, 1), dim3(512), W7::LDS_BYTES, st, a);
   return dvc::check_launch("conv_wgrad7_kernel");
 }
 
@@ -803,7 +828,7 @@ extern "C" int dvc_conv2d_wgrad(const DvcSrc* srcs, int32_t n_src, int32_t batch
   if (p.thin_parts > 0) rc = ksize == 3 ? launch_thin<3>(a, p, st) : launch_thin<7>(a, p, st);
   else if (ksize == 3) rc = stride == 1 ? launch_block<3, 1>(a, p, st) : launch_block<3, 2>(a, p, st);
   else if (ksize == 1) rc = stride == 1 ? launch_block<1, 1>(a, p, st) : launch_block<1, 2>(a, p, st);
-  else rc = launch7(a, p, st);
+  else rc = cin <= 8 ? launch7<true>(a, p, st) : launch7<false>(a, p, st);
   if (rc) return rc;
   const long long total = (long long)out_channels * cin * p.taps + out_channels;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dvc::stream_grid(total, 64)), dim3(256), 0, st, scratch, grad_weight,

@@ -189,10 +189,13 @@ def test_conv2d_wgrad_large_reduction():
     (3, 8, 4, 2, 33, 40, None),       # four thread groups per tile
     (7, 18, 1, 1, 20, 70, 0.0),       # the widest 7x7 input the form takes
     (3, 64, 3, 2, 45, 83, 0.01),      # the reconstruction layer: past the form's limit, on the matrix cores
+    (7, 8, 32, 2, 64, 96, None),      # the first layer of a motion-estimation level: 8 channels x 4 taps per block
+    (7, 5, 40, 1, 37, 50, 0.0),       # the same form with fewer channels, two output blocks, ragged tiles
 ])
-def test_conv2d_wgrad_thin_layers(k, cin, cout, n, h, w, slope):
-    """Layers with <= 4 output channels and Cin x k <= 128 take the vector-ALU weight-gradient kernel: against torch
-    autograd, with the input split over two concatenated sources."""
+def test_conv2d_wgrad_thin_and_narrow_layers(k, cin, cout, n, h, w, slope):
+    """Layers with <= 4 output channels and Cin x k <= 128 take the vector-ALU weight-gradient kernel, 7x7 layers with
+    <= 8 input channels the narrow-input form of the matrix-core kernel: against torch autograd, with the input split
+    over two concatenated sources."""
     from deepvideocodec_amd import ops
     g = torch.Generator().manual_seed(k * 100 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
