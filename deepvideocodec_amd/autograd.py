@@ -30,8 +30,11 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, precision,
-                dgrad_precision, *srcs):
+                dgrad_precision, residual, residual2, *srcs):
+        # (residual operands only for a layer without output activation: the sum's adjoint is then the identity on
+        # every operand and needs nothing saved; see conv2d() below)
         out = ops.conv2d(srcs, weight, bias, stride=stride, in_slope=in_slope, out_slope=out_slope,
+                         residual=residual, residual2=residual2,
                          pixel_shuffle=pixel_shuffle, packed=packed, precision=precision)
         ctx.cfg = (stride, in_slope, out_slope, pixel_shuffle, bias is not None)
         ctx.dgrad_packed = dgrad_packed     # the layer's cached data-gradient weight image (or None: packed on demand)
@@ -61,7 +64,7 @@ class _Conv2d(torch.autograd.Function):
         elif has_bias and need[1]:
             gb = ops.plane_dot(g_pre, None, sum_batch=True)
         gsrcs = [None] * len(srcs)
-        if any(need[10:]):
+        if any(need[12:]):
             # data gradient = stride-1 convolution of (zero-upsampled) g_pre with the flipped,
             # transposed kernel -- the same MFMA kernel as the forward pass (and in the same operand mode)
             gin = ops.zero_upsample2(g_pre, h, w) if stride == 2 else g_pre
@@ -70,11 +73,12 @@ class _Conv2d(torch.autograd.Function):
             c0 = 0
             for i, s in enumerate(srcs):
                 c1 = c0 + s.size(1)
-                if need[10 + i]:
+                if need[12 + i]:
                     gs = gx[:, c0:c1]
                     gsrcs[i] = ops.mul_act_grad(gs, s, in_slope) if in_slope is not None else gs
                 c0 = c1
-        return (gw, gb, None, None, None, None, None, None, None, None, *gsrcs)
+        return (gw, gb, None, None, None, None, None, None, None, None, g if need[10] else None,
+                g if need[11] else None, *gsrcs)
 
 
 def dgrad_weight_image(weight: Tensor, precision: int = 0) -> Tensor:
@@ -87,14 +91,19 @@ def dgrad_weight_image(weight: Tensor, precision: int = 0) -> Tensor:
 
 def conv2d(srcs, weight, bias, stride=1, in_slope=None, out_slope=None, residual=None, res_scale=None,
            residual2=None, pixel_shuffle=False, packed=None, dgrad_packed=None, precision=0, dgrad_precision=0):
-    """Differentiable ops.conv2d.  The residual adds are taken out of the convolution epilogue
-    (their adjoint needs the pre-residual activation) and run as add_scaled.  `precision` / `dgrad_precision`: operand
+    """Differentiable ops.conv2d.  Behind an output activation, or with a gate, the residual adds are taken out of the
+    convolution epilogue (their adjoint needs the pre-residual activation) and run as add_scaled.  `precision` / `dgrad_precision`: operand
     mode (ops.PRECISIONS) of the forward and of the data-gradient convolution -- `packed` / `dgrad_packed` must be images
     in those modes; the weight gradient is always formed in fp32."""
     if isinstance(srcs, torch.Tensor):
         srcs = (srcs,)
+    if residual is not None and out_slope is None and res_scale is None and not pixel_shuffle:
+        # no activation between the convolution and the sum (the second convolution of a ResBlock,
+        # dmc/models/layers.py:75-81): the sum stays in the convolution's epilogue, as on the coding path
+        return _Conv2d.apply(weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, precision,
+                             dgrad_precision, residual, residual2, *srcs)
     y = _Conv2d.apply(weight, bias, stride, in_slope, out_slope, pixel_shuffle, packed, dgrad_packed, precision,
-                      dgrad_precision, *srcs)
+                      dgrad_precision, None, None, *srcs)
     if residual is not None:
         y = add_scaled(y, residual, res_scale, residual2)
     return y
