@@ -97,14 +97,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(unsigned long long 
 // output rows per staged pixel tile (x 32 columns)
 constexpr int tile_rows(int ks, int s) { return ks == 7 ? 4 : (s == 2 && ks == 3) ? WG_TH_S2 : WG_TH_S1; }
 
-template <int KS, int S, int MT, int CT>
+// TW: output pixels per tile row.  32, or 16 (with twice the rows) for planes at most 16 pixels wide -- the latent
+// layers of a 256 x 256 training crop are 16 x 16, and half of every 32-pixel row was padding.
+template <int KS, int S, int MT, int CT, int TW_ = 32>
 struct WGeo {
   static constexpr int KG = 8 / (MT * CT);      // waves sharing one corner (pixel-pair interleave)
   static constexpr int XCH = 32 * CT, GCH = 32 * MT;   // staged input / gradient channels
   static_assert(KS == 1 || KS == 3, "7x7 has its own kernel");
   static constexpr int KH = KS;
   static constexpr int TAPS = KS * KS;
-  static constexpr int TH = tile_rows(KS, S), TW = 32, PAD = KS / 2;
+  static_assert(TW_ == 32 || TW_ == 16, "tile rows of 32 or 16 pixels");
+  static constexpr int TW = TW_, TH = tile_rows(KS, S) * (32 / TW_), PAD = KS / 2;
   static constexpr int SL = (KS == 1) ? 1 : S;   // pixel stride inside the LDS tile
   static constexpr int GS = (KS == 1) ? S : 1;   // global step between staged pixels
   static constexpr int IH = (TH - 1) * SL + KH, IW = (TW - 1) * SL + KS;
@@ -115,9 +118,9 @@ struct WGeo {
   static constexpr int LDS_BYTES = (STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS) * 4;
 };
 
-template <int KS, int S, int MT, int CT>
+template <int KS, int S, int MT, int CT, int TW = 32>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
-  using G = WGeo<KS, S, MT, CT>;
+  using G = WGeo<KS, S, MT, CT, TW>;
   constexpr int KG = G::KG, XCH = G::XCH, GCH = G::GCH, XPW = XCH / 8, GPW = GCH / 8;   // channels staged per wave
   constexpr int TAPS = G::TAPS, TH = G::TH, SL = G::SL, GS = G::GS, IW = G::IW, XE = G::XE, XSTR = G::XSTR;
   constexpr int XSLOTS = G::XSLOTS, GE = G::GE, GSTR = G::GSTR, GSLOTS = G::GSLOTS, PAD = G::PAD, KH = G::KH;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     pf_live = t < a.n_tiles ? 0xffffffffu : 0u;
     const int n = t / per_n, r = t - n * per_n;
     const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int oy0 = ty * TH, ox0 = tx * TW;
     const int gy0 = (KS == 1) ? oy0 * S : oy0 * S - PAD;
     const int gx0 = (KS == 1) ? ox0 * S : ox0 * S - PAD;
     pf_n = n;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < GSLOTS; ++j) {
-      const int row = 2 * j + (lane >> 5), col = lane & 31;
+      const int row = (lane + 64 * j) / TW, col = (lane + 64 * j) % TW;
       const int oy = oy0 + row, ox = ox0 + col;
       const bool ok = lane + 64 * j < GE && oy < a.ho && ox < a.wo;
       goff[j] = ok ? 4u * (unsigned)(oy * a.wo + ox) : 0x80000000u;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 
   const float* const a_base = g_s + (mt * 32 + l32) * GSTR + half + 2 * grp;
   const float* const b_base = x_s + (ct * 32 + l32) * XSTR + (half + 2 * grp) * SL;
-  static_assert(32 % (2 * KG) == 0 && GE % (2 * KG) == 0, "pixel-pair interleave must tile a row");
+  static_assert(TW % (2 * KG) == 0 && GE % (2 * KG) == 0, "pixel-pair interleave must tile a row");
   constexpr int NPAIR = GE / (2 * KG);                     // pixel pairs per wave and tile
   constexpr int NPIECE = XPW + GPW;
   constexpr int PPS = (NPIECE + NPAIR - 1) / NPAIR;        // load pieces issued after each pair
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     prefetch_setup(t + nsplit);
 #pragma unroll
     for (int jj = 0; jj < NPAIR; ++jj) {   // this wave's pixel pairs: pixels 2 KG jj + 2 grp, + 1
-      const int row = (2 * KG * jj) / 32, px = (2 * KG * jj) % 32;
-      const float av = a_base[row * 32 + px];
+      const int row = (2 * KG * jj) / TW, px = (2 * KG * jj) % TW;
+      const float av = a_base[row * TW + px];
 #pragma unroll
       for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
 
 struct Plan {
   int ho, wo, th, tiles_x, tiles_y, n_tiles, cout_pad, cin_pad, n_cib, blocks, nsplit, taps, mt, ct;
+  int tw;           // pixels per tile row (32; 16 for 3x3 stride-1 layers on planes at most 16 wide)
   int thin_parts;   // > 0: the vector-ALU kernel for <= 4 output channels, with this many thread groups per tile
 };
 
@@ -677,8 +681,9 @@ int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Pl
   const int pad = ks / 2;
   p->ho = (h + 2 * pad - ks) / stride + 1;
   p->wo = (w + 2 * pad - ks) / stride + 1;
-  p->th = tile_rows(ks, stride);
-  p->tiles_x = (p->wo + 31) / 32;
+  p->tw = (ks == 3 && stride == 1 && p->wo <= 16 && cout > 4) ? 16 : 32;
+  p->th = tile_rows(ks, stride) * (32 / p->tw);
+  p->tiles_x = (p->wo + p->tw - 1) / p->tw;
   p->tiles_y = (p->ho + p->th - 1) / p->th;
   const long long nt = (long long)batch * p->tiles_x * p->tiles_y;
   DVC_REQUIRE(nt < (1LL << 30), "%s: too many tiles", who);
@@ -718,9 +723,9 @@ int make_plan(int cout, int cin, int ks, int stride, int batch, int h, int w, Pl
   return DVC_OK;
 }
 
-template <int KS, int S, int MT, int CT>
+template <int KS, int S, int MT, int CT, int TW = 32>
 int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
-  using G = WGeo<KS, S, MT, CT>;
+  using G = WGeo<KS, S, MT, CT, TW>;
   // LDS above the 64 KiB default needs an opt-in per kernel and per device; calls may come from
   // several host threads, so the done-mask is atomic (setting the attribute twice is harmless)
   static std::atomic<unsigned long long> attr_done{0};
@@ -728,7 +733,7 @@ int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 63) device = 0;
   const unsigned long long device_bit = 1ull << device;
   if (!(attr_done.load(std::memory_order_acquire) & device_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, S, MT, CT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS, S, MT, CT, TW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) {
       dvc::set_error("hipFuncSetAttribute(wgrad %d,%d): %s", KS, S, hipGetErrorString(e));
@@ -737,7 +742,7 @@ int launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
     attr_done.fetch_or(device_bit, std::memory_order_release);
   }
   dim3 grid(p.nsplit, p.blocks, 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, MT, CT>), grid, dim3(512), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, MT, CT, TW>), grid, dim3(512), G::LDS_BYTES, st, a);
   return dvc::check_launch("conv_wgrad_kernel");
 }
 
@@ -772,6 +777,12 @@ int launch_thin(const WgradArgs& a, const Plan& p, hipStream_t st) {
 
 template <int KS, int S>
 int launch_block(const WgradArgs& a, const Plan& p, hipStream_t st) {
+  if constexpr (KS == 3 && S == 1) {
+    if (p.tw == 16) {
+      if (p.mt == 2) return p.ct == 2 ? launch<3, 1, 2, 2, 16>(a, p, st) : launch<3, 1, 2, 1, 16>(a, p, st);
+      return p.ct == 2 ? launch<3, 1, 1, 2, 16>(a, p, st) : launch<3, 1, 1, 1, 16>(a, p, st);
+    }
+  }
   if (p.mt == 2) return p.ct == 2 ? launch<KS, S, 2, 2>(a, p, st) : launch<KS, S, 2, 1>(a, p, st);
   return p.ct == 2 ? launch<KS, S, 1, 2>(a, p, st) : launch<KS, S, 1, 1>(a, p, st);
 }

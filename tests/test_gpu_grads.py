@@ -214,6 +214,23 @@ def test_conv2d_wgrad_thin_and_narrow_layers(k, cin, cout, n, h, w, slope):
     assert torch.equal(gw1, gw)       # one source or two: the same sums in the same order
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w", [(40, 72, 3, 13, 16), (32, 32, 4, 8, 8), (96, 24, 2, 16, 11), (192, 128, 8, 16, 16)])
+def test_conv2d_wgrad_narrow_planes(cin, cout, n, h, w):
+    """3x3 stride-1 layers on planes at most 16 pixels wide (the latent layers of a training crop) use tiles of
+    8 x 16 instead of 4 x 32 pixels: all four block shapes, ragged rows and columns, against torch autograd."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).requires_grad_()
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(F.leaky_relu(x, 0.2), wt, b, padding=1)
+    R = torch.randn(y.shape, generator=g)
+    (y * R).sum().backward()
+    gw, gb = ops.conv2d_wgrad(dev(x), dev(R), wt.shape, 1, in_slope=0.2, with_bias=True)
+    close(gw, wt.grad, rel=5e-5, what="grad weight")
+    close(gb, b.grad, rel=5e-5, what="grad bias")
+
+
 def test_residual_and_gate_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(11)
