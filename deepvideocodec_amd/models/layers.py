@@ -76,7 +76,8 @@ class Conv2d(nn.Module):
                 pixel_shuffle=False, out=None, plane_sums=False):
         """`plane_sums=True` (inference only): returns (out, sums), see ops.conv2d."""
         if torch.is_grad_enabled():
-            # training path: same forward kernel, on the autograd tape (residual adds un-fused)
+            # training path: same forward kernel, on the autograd tape (residual adds un-fused where an output
+            # activation or a gate sits in front of them)
             if out is not None:
                 raise ValueError("Conv2d: `out=` is an inference-only option (call under torch.no_grad())")
             pf, pd = self._train_precisions()
