@@ -314,6 +314,27 @@ def test_warp_gradients_noisy_flow(sigma):
     close(dl.grad, cl.grad, rel=1e-3, what="grad flow")
 
 
+def test_warp_gradient_keeps_non_finite_values():
+    """The adjoint's LDS sums are fixed point, scaled by the tile's largest |gradient|; a tile whose gradients are not
+    all finite must fall back to float sums for that channel, so that a NaN or Inf still reaches the source gradient
+    (and only the elements that pixel touches)."""
+    from deepvideocodec_amd import ops
+    g = torch.Generator().manual_seed(21)
+    src = torch.randn(1, 5, 40, 64, generator=g)
+    flow = torch.randn(1, 2, 40, 64, generator=g) * 1.5
+    go = torch.randn(1, 5, 40, 64, generator=g)
+    go[0, 1, 17, 33] = float("nan")
+    go[0, 3, 5, 9] = float("inf")
+    cs = src.clone().requires_grad_()
+    (O.flow_warp(cs, flow) * go).sum().backward()     # (nan * 1 -> nan, inf * weight -> inf in the reference's adjoint)
+    gs, _ = ops.flow_warp_backward(dev(src), dev(flow), dev(go))
+    gs = gs.cpu()
+    assert torch.equal(torch.isnan(gs), torch.isnan(cs.grad))
+    assert torch.equal(torch.isinf(gs), torch.isinf(cs.grad))
+    fin = torch.isfinite(cs.grad)
+    assert float((gs[fin] - cs.grad[fin]).abs().max()) <= 2e-5 * float(cs.grad[fin].abs().max())
+
+
 def test_pool_and_upsample_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(4)
