@@ -21,10 +21,12 @@ def psnr(x, rec):
     return -10.0 * math.log10(torch.mean((x.double() - rec.double()) ** 2).item())
 
 
-def code_gop(enc_fn, dec_fn, frames, to_dev, clamp):
+def code_gop(enc_fn, dec_fn, frames, to_dev, clamp, tag=""):
     dpb = {"x_ref": to_dev(frames[0]), "feature_ref": None, "y_ref": None, "y_mv_ref": None}
     out = []
     for x in frames[1:]:
+        if tag:   # (a sign of life per frame: the oracle needs ~12 s for each)
+            print(f"  [{tag}] frame {len(out) + 1} of {len(frames) - 1}", file=sys.stderr, flush=True)
         enc = enc_fn(to_dev(x), dpb)
         rec, info = dec_fn(enc["strings"], enc["shape"], dpb)
         rec = clamp(rec)
@@ -64,7 +66,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ref = code_gop(lambda x, d: O.encode_inter(sd, ent, x, d), lambda s, sh, d: O.decode_inter(sd, ent, s, sh, d),
-                       frames, lambda t: t, lambda t: t.clamp(0, 1))
+                       frames, lambda t: t, lambda t: t.clamp(0, 1), tag="oracle")
         t2 = time.perf_counter()
     n = len(got)
     for i, ((bg, pg, sg), (br, pr, sr)) in enumerate(zip(got, ref), start=1):
