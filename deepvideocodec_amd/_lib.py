@@ -93,6 +93,7 @@ SIGNATURES = {
     "dvc_conv2d_wgrad": (C.c_int, [_SRC, _i32, _i32, _i32, _i32, _i32, _f32, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "dvc_act_grad": (C.c_int, [_SRC, _SRC, _f32, _i32, _P, _i32, _i32, _i32, _i32, _P]),
     "dvc_mul_act_grad": (C.c_int, [_SRC, _SRC, _f32, _DST, _i32, _i32, _i32, _P]),
+    "dvc_mul_act_grad_add": (C.c_int, [_SRC, _SRC, _f32, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_zero_upsample2": (C.c_int, [_SRC, _DST, _i32, _i32, _i32, _i32, _i32, _P]),
     "dvc_add_scaled": (C.c_int, [_SRC, _SRC, _P, _SRC, _DST, _i32, _i32, _i32, _P]),
     "dvc_scale_planes": (C.c_int, [_SRC, _P, _DST, _i32, _i32, _i32, _P]),

@@ -109,6 +109,73 @@ def conv2d(srcs, weight, bias, stride=1, in_slope=None, out_slope=None, residual
     return y
 
 
+class _ResBlock(torch.autograd.Function):
+    """x + last(conv2(act(conv1(first(x))))) (+ plus) as ONE node of the tape (dmc/models/layers.py:59-81).  Node by node,
+    x collects two gradients -- the block's output gradient along the sum and the first convolution's data gradient --
+    which autograd adds in a pass of its own; here the sum is formed where the data gradient is finished: inside
+    mul_act_grad when the block starts with an activation, in the data-gradient convolution's epilogue when it does
+    not.  The saved tensors and every other kernel are those of the node-by-node form."""
+
+    @staticmethod
+    def forward(ctx, x, plus, w1, b1, w2, b2, slope_in, slope_mid, slope_out, packed1, packed2, dpacked1, dpacked2,
+                pf1, pd1, pf2, pd2):
+        t = ops.conv2d(x, w1, b1, in_slope=slope_in, out_slope=slope_mid, packed=packed1, precision=pf1)
+        if slope_out is None:
+            y = ops.conv2d(t, w2, b2, residual=x, residual2=plus, packed=packed2, precision=pf2)
+            u = None
+        else:
+            u = ops.conv2d(t, w2, b2, out_slope=slope_out, packed=packed2, precision=pf2)
+            y = ops.add_scaled(u, x, None, plus)
+        ctx.cfg = (slope_in, slope_mid, slope_out, pd1, pd2)
+        ctx.images = (dpacked1, dpacked2)
+        ctx.save_for_backward(x, t, u, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        slope_in, slope_mid, slope_out, pd1, pd2 = ctx.cfg
+        dpacked1, dpacked2 = ctx.images
+        x, t, u, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        n, ch, h, w = x.shape
+        mid = w1.shape[0]
+        g = _rows_ok(g)
+        # second convolution
+        if slope_out is None and g.is_contiguous():
+            g2 = g
+        else:
+            g2 = ops.act_grad(g, u, 1.0 if slope_out is None else slope_out, False, (n, ch, h, w))
+        gw2 = gb2 = gw1 = gb1 = None
+        if need[4] or need[5]:
+            gw2, gb2 = ops.conv2d_wgrad((t,), g2, w2.shape, 1, None, with_bias=True)
+        image2 = dpacked2 if dpacked2 is not None else dgrad_weight_image(w2, pd2)
+        gt = ops.conv2d(g2, (mid, ch, 3, 3), None, stride=1, packed=image2, precision=pd2)
+        # first convolution (its output activation is the block's middle one)
+        g1 = ops.act_grad(gt, t, slope_mid, False, (n, mid, h, w))
+        if need[2] or need[3]:
+            gw1, gb1 = ops.conv2d_wgrad((x,), g1, w1.shape, 1, slope_in, with_bias=True)
+        gx = None
+        if need[0]:
+            image1 = dpacked1 if dpacked1 is not None else dgrad_weight_image(w1, pd1)
+            if slope_in is None:
+                gx = ops.conv2d(g1, (ch, mid, 3, 3), None, stride=1, packed=image1, precision=pd1, residual=g)
+            else:
+                gx = ops.conv2d(g1, (ch, mid, 3, 3), None, stride=1, packed=image1, precision=pd1)
+                gx = ops.mul_act_grad(gx, x, slope_in, out=gx, plus=g)
+        return (gx, g if need[1] else None, gw1 if need[2] else None, gb1 if need[3] else None,
+                gw2 if need[4] else None, gb2 if need[5] else None,
+                None, None, None, None, None, None, None, None, None, None, None)
+
+
+def res_block(x, plus, conv1, conv2, slope_in, slope_mid, slope_out):
+    """Differentiable ResBlock over two Conv2d layers of the mirror (`plus`: an extra tensor added to the result)."""
+    pf1, pd1 = conv1._train_precisions()
+    pf2, pd2 = conv2._train_precisions()
+    return _ResBlock.apply(x, plus, conv1.weight, conv1.bias, conv2.weight, conv2.bias, slope_in, slope_mid, slope_out,
+                           conv1.packed_weight(pf1), conv2.packed_weight(pf2), conv1.dgrad_weight(pd1),
+                           conv2.dgrad_weight(pd2), pf1, pd1, pf2, pd2)
+
+
 class _AddScaled(torch.autograd.Function):
     """a + b * scale[n, c] (+ c2)."""
 

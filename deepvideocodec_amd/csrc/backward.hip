@@ -55,15 +55,19 @@ __global__ __launch_bounds__(256) void act_grad_kernel(Src g, Src t, int has_t, 
   }
 }
 
-// out = g * (x > 0 ? 1 : slope): the input-activation derivative applied to a data gradient
-__global__ __launch_bounds__(256) void mul_act_grad_kernel(Src g, Src x, Dst out, float slope, int batch, int h, int w) {
+// out = g * (x > 0 ? 1 : slope) (+ plus): the input-activation derivative applied to a data gradient, and
+// optionally the gradient that reaches x along another path added in the same pass
+__global__ __launch_bounds__(256) void mul_act_grad_kernel(Src g, Src x, Src plus, int has_plus, Dst out, float slope,
+                                                           int batch, int h, int w) {
   const long long hw = (long long)h * w;
   FOREACH((long long)batch * g.c * hw) {
     const long long pix = i % hw;
     const long long q = i / hw;
     const int c = (int)(q % g.c), n = (int)(q / g.c);
     const float gv = g.p[n * g.bs + c * g.cs + pix];
-    out.p[n * out.bs + c * out.cs + pix] = x.p[n * x.bs + c * x.cs + pix] > 0.f ? gv : gv * slope;
+    float v = x.p[n * x.bs + c * x.cs + pix] > 0.f ? gv : gv * slope;
+    if (has_plus) v += plus.p[n * plus.bs + c * plus.cs + pix];
+    out.p[n * out.bs + c * out.cs + pix] = v;
   }
 }
 
@@ -136,14 +140,18 @@ __global__ __launch_bounds__(256) void act_grad4_kernel(Src g, Src t, int has_t,
   }
 }
 
-__global__ __launch_bounds__(256) void mul_act_grad4_kernel(Src g, Src x, Dst out, float slope, unsigned chans,
-                                                            unsigned plane4, unsigned total) {
+__global__ __launch_bounds__(256) void mul_act_grad4_kernel(Src g, Src x, Src plus, int has_plus, Dst out, float slope,
+                                                            unsigned chans, unsigned plane4, unsigned total) {
   FOREACH4(total) {
     const unsigned p4 = i % plane4, q = i / plane4, c = q % chans, n = q / chans;
     float4 v = plane4_of(g, n, c)[p4];
     const float4 a = plane4_of(x, n, c)[p4];
     v.x = a.x > 0.f ? v.x : v.x * slope; v.y = a.y > 0.f ? v.y : v.y * slope;
     v.z = a.z > 0.f ? v.z : v.z * slope; v.w = a.w > 0.f ? v.w : v.w * slope;
+    if (has_plus) {
+      const float4 e = plane4_of(plus, n, c)[p4];
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
     plane4_of(out, n, c)[p4] = v;
   }
 }
@@ -622,25 +630,36 @@ extern "C" int dvc_act_grad(const DvcSrc* grad, const DvcSrc* act_out, float slo
   return dvc::check_launch("act_grad_kernel");
 }
 
-extern "C" int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcDst* out, int32_t batch,
-                                int32_t h, int32_t w, void* stream) {
+extern "C" int dvc_mul_act_grad_add(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcSrc* plus,
+                                    const DvcDst* out, int32_t batch, int32_t h, int32_t w, void* stream) {
   DVC_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "dvc_mul_act_grad: bad dims");
   const long long plane = (long long)h * w;
   CHECK_SRC(grad, plane, "dvc_mul_act_grad(grad)");
   CHECK_SRC(x, plane, "dvc_mul_act_grad(x)");
   DVC_REQUIRE(x->channels == grad->channels, "dvc_mul_act_grad: channel mismatch");
+  if (plus != nullptr) {
+    CHECK_SRC(plus, plane, "dvc_mul_act_grad(plus)");
+    DVC_REQUIRE(plus->channels == grad->channels, "dvc_mul_act_grad: channel mismatch (plus)");
+  }
   CHECK_DST(out, plane, "dvc_mul_act_grad");
+  const Src pl = plus != nullptr ? mk(plus) : mk(grad);
+  const int has_plus = plus != nullptr ? 1 : 0;
   {
     const long long total = (long long)batch * grad->channels * plane;
-    if (plane % 4 == 0 && total / 4 < (1LL << 31) && al16(grad) && al16(x) && al16(out)) {
-      LAUNCH_1D(mul_act_grad4_kernel, total / 4, stream, mk(grad), mk(x), mk(out), slope, (unsigned)grad->channels,
-                (unsigned)(plane / 4), (unsigned)(total / 4));
+    if (plane % 4 == 0 && total / 4 < (1LL << 31) && al16(grad) && al16(x) && al16(out) && (plus == nullptr || al16(plus))) {
+      LAUNCH_1D(mul_act_grad4_kernel, total / 4, stream, mk(grad), mk(x), pl, has_plus, mk(out), slope,
+                (unsigned)grad->channels, (unsigned)(plane / 4), (unsigned)(total / 4));
       return dvc::check_launch("mul_act_grad4_kernel");
     }
   }
-  LAUNCH_1D(mul_act_grad_kernel, (long long)batch * grad->channels * plane, stream, mk(grad), mk(x), mk(out), slope,
-            batch, h, w);
+  LAUNCH_1D(mul_act_grad_kernel, (long long)batch * grad->channels * plane, stream, mk(grad), mk(x), pl, has_plus, mk(out),
+            slope, batch, h, w);
   return dvc::check_launch("mul_act_grad_kernel");
+}
+
+extern "C" int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcDst* out, int32_t batch,
+                                int32_t h, int32_t w, void* stream) {
+  return dvc_mul_act_grad_add(grad, x, slope, nullptr, out, batch, h, w, stream);
 }
 
 extern "C" int dvc_zero_upsample2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,

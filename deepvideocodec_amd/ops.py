@@ -471,12 +471,17 @@ def act_grad(grad: Tensor, act_out: Optional[Tensor], slope: float, pixel_shuffl
     return out
 
 
-def mul_act_grad(grad: Tensor, x: Tensor, slope: float, out: Optional[Tensor] = None) -> Tensor:
+def mul_act_grad(grad: Tensor, x: Tensor, slope: float, out: Optional[Tensor] = None,
+                 plus: Optional[Tensor] = None) -> Tensor:
+    """grad * (x > 0 ? 1 : slope) (+ plus)."""
     n, c, h, w = grad.shape
     if out is None:
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=grad.device)
-    check(_lib.load().dvc_mul_act_grad(C.byref(_src(grad, "grad")), C.byref(_src(x, "x")), float(slope),
-                                       C.byref(_dst(out)), n, h, w, _stream()), "dvc_mul_act_grad")
+    if plus is not None and tuple(plus.shape) != (n, c, h, w):
+        raise ValueError(f"mul_act_grad: plus shape {tuple(plus.shape)} != {(n, c, h, w)}")
+    check(_lib.load().dvc_mul_act_grad_add(C.byref(_src(grad, "grad")), C.byref(_src(x, "x")), float(slope),
+                                           C.byref(_src(plus, "plus")) if plus is not None else None,
+                                           C.byref(_dst(out)), n, h, w, _stream()), "dvc_mul_act_grad")
     return out
 
 

@@ -304,6 +304,11 @@ int dvc_act_grad(const DvcSrc* grad, const DvcSrc* act_out, float slope, int32_t
 /* out = grad * (x > 0 ? 1 : slope): derivative of the fused input activation. */
 int dvc_mul_act_grad(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcDst* out,
                      int32_t batch, int32_t h, int32_t w, void* stream);
+/* out = grad * (x > 0 ? 1 : slope) + plus (plus NULL: the function above).  x of a ResBlock feeds its first
+ * convolution through an activation and the block's sum directly (layers.py:75-81): its gradient is the masked
+ * data gradient plus the block's output gradient, formed here in one pass instead of by an autograd accumulation. */
+int dvc_mul_act_grad_add(const DvcSrc* grad, const DvcSrc* x, float slope, const DvcSrc* plus, const DvcDst* out,
+                         int32_t batch, int32_t h, int32_t w, void* stream);
 /* out (out_h x out_w) = src (h x w) on the even sites, zero elsewhere: turns the data gradient
  * of a stride-2 convolution into a stride-1 convolution with the flipped kernel. */
 int dvc_zero_upsample2(const DvcSrc* src, const DvcDst* out, int32_t batch, int32_t h, int32_t w,

@@ -231,6 +231,46 @@ def test_conv2d_wgrad_narrow_planes(cin, cout, n, h, w):
     close(gb, b.grad, rel=5e-5, what="grad bias")
 
 
+@pytest.mark.parametrize("start_relu,end_relu,bottleneck,slope,with_plus", [
+    (True, False, False, 0.01, False),    # the default block (layers.py:59-81)
+    (True, True, True, 0.1, False),       # bottleneck block of the contextual coder: activation in and out
+    (False, False, False, 0.0, True),     # no input activation (the sum rides in the data-gradient epilogue), ReLU, extra addend
+    (True, False, False, 0.01, True),
+])
+def test_res_block_as_one_tape_node(start_relu, end_relu, bottleneck, slope, with_plus):
+    """Under autograd a ResBlock is one node whose backward forms x's gradient (output gradient + masked data gradient)
+    inside a kernel: forward, input / addend gradients and the four parameter gradients against plain PyTorch."""
+    from deepvideocodec_amd.models.layers import ResBlock
+    torch.manual_seed(17)
+    blk = ResBlock(32, slope=slope, start_from_relu=start_relu, end_with_relu=end_relu, bottleneck=bottleneck)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 24, 40, generator=g)
+    p = torch.randn(2, 32, 24, 40, generator=g) if with_plus else None
+    act = (lambda t: F.relu(t)) if blk.slope == 0.0 else (lambda t: F.leaky_relu(t, blk.slope))
+    cx = x.clone().requires_grad_()
+    cp = p.clone().requires_grad_() if with_plus else None
+    ref_params = [t.detach().clone().requires_grad_() for t in (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)]
+    t = act(F.conv2d(act(cx) if start_relu else cx, ref_params[0], ref_params[1], padding=1))
+    t = F.conv2d(t, ref_params[2], ref_params[3], padding=1)
+    y_ref = cx + (act(t) if end_relu else t)
+    if with_plus:
+        y_ref = y_ref + cp
+    R = torch.randn(y_ref.shape, generator=g)
+    (y_ref * R).sum().backward()
+    blk = blk.to("cuda:0")
+    dx = dev(x).requires_grad_()
+    dp = dev(p).requires_grad_() if with_plus else None
+    y = blk(dx, plus=dp)
+    assert type(y.grad_fn).__name__ == "_ResBlockBackward"
+    close(y, y_ref.detach(), what="forward")
+    (y * dev(R)).sum().backward()
+    close(dx.grad, cx.grad, what="grad x")
+    if with_plus:
+        close(dp.grad, cp.grad, what="grad plus")
+    for name, a, b in zip(("w1", "b1", "w2", "b2"), (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias), ref_params):
+        close(a.grad, b.grad, rel=5e-5, what="grad " + name)
+
+
 def test_residual_and_gate_gradients():
     from deepvideocodec_amd import autograd as A
     g = torch.Generator().manual_seed(11)
